@@ -1,0 +1,168 @@
+"""ctypes binding of libdfdclip_hip.so (C ABI declared in include/dfdclip.h).
+
+There is no CPU or PyTorch fallback: if the library is missing or a call fails, this module
+raises.  Tensors are passed as raw device pointers; every call enqueues on
+`torch.cuda.current_stream()` and returns without synchronising.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT = range(5)
+ABI_VERSION = 1
+
+_DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+class DfdError(RuntimeError):
+    pass
+
+
+class GemmExtra(Structure):
+    _fields_ = [("pos", c_void_p), ("cls", c_void_p), ("k_export", c_void_p), ("v_export", c_void_p),
+                ("tokens", c_int32), ("frames_per_clip", c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/dfdclip.h one to one
+SIGNATURES = {
+    "dfd_last_error": (c_char_p, []),
+    "dfd_abi_version": (c_int, []),
+    "dfd_device_check": (c_int, []),
+    "dfd_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_float, c_void_p]),
+    "dfd_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dfd_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int,
+                         POINTER(GemmExtra), c_int64, c_int, c_int, c_void_p]),
+    "dfd_attention_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "dfd_linear_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "dfd_decoder_attn_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dfd_decoder_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dfd_head_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                             c_int, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the kernel library and bind every declared symbol.  Raises DfdError when the
+    file is absent (run `python -c "import __graft_entry__ as g; g.build()"` or
+    `python dfd-clip_amd/build.py`), a symbol is missing or the ABI version differs."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise DfdError(f"{path} not found: the HIP kernel library is not built and there is no fallback path")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise DfdError(f"{path} does not export {name}")
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dfd_abi_version() != ABI_VERSION:
+        raise DfdError(f"{path}: ABI version {lib.dfd_abi_version()} != {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise DfdError(f"{what} failed ({rc}): {load_library().dfd_last_error().decode()}")
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DfdError("HIP kernels need device tensors; got a CPU tensor (there is no CPU path)")
+
+
+def layernorm(x, gamma, beta, out, eps=1e-5):
+    """out[rows, cols] = LayerNorm(x[rows, cols]); x f32; out f32 (may alias x) or bf16."""
+    _dev(x, gamma, beta, out)
+    assert x.dtype == torch.float32 and x.dim() == 2 and out.shape == x.shape
+    assert x.stride(1) == 1 and out.stride(1) == 1
+    _check(load_library().dfd_layernorm(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(out), out.stride(0),
+                                        _DTYPE[out.dtype], x.shape[0], x.shape[1], eps, _stream()), "dfd_layernorm")
+    return out
+
+
+def patchify(frames, out, res, patch):
+    _dev(frames, out)
+    assert frames.dtype == torch.float32 and frames.is_contiguous() and out.is_contiguous()
+    n = frames.shape[0]
+    _check(load_library().dfd_patchify(_ptr(frames), _ptr(out), _DTYPE[out.dtype], n, res, patch, out.shape[1], _stream()),
+           "dfd_patchify")
+    return out
+
+
+def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_export=None, v_export=None, tokens=0,
+         frames_per_clip=0):
+    """c = epilogue(a[M,K] @ w[N,K]^T).  `m` limits the rows used (buffers may be over-allocated)."""
+    _dev(a, w, c, bias, pos, cls, k_export, v_export)
+    assert a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1 and c.stride(1) == 1
+    M = a.shape[0] if m is None else m
+    N, K = w.shape
+    assert a.shape[1] == K
+    extra = GemmExtra(_ptr(pos).value, _ptr(cls).value, _ptr(k_export).value, _ptr(v_export).value, tokens, frames_per_clip)
+    _check(load_library().dfd_gemm(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _DTYPE[a.dtype], _ptr(c), c.stride(0),
+                                   _DTYPE[c.dtype], _ptr(bias), epilogue, ctypes.byref(extra), M, N, K, _stream()), "dfd_gemm")
+    return c
+
+
+def attention_fwd(qkv, out, n_frames, tokens, heads, head_dim=64):
+    _dev(qkv, out)
+    assert qkv.dtype == out.dtype and qkv.stride(1) == 1 and out.stride(1) == 1
+    _check(load_library().dfd_attention_fwd(_ptr(qkv), qkv.stride(0), _ptr(out), out.stride(0), _DTYPE[qkv.dtype], n_frames,
+                                            tokens, heads, head_dim, head_dim ** -0.5, _stream()), "dfd_attention_fwd")
+    return out
+
+
+def linear_rows(x, w, bias, y, epilogue=EPI_BIAS):
+    _dev(x, w, bias, y)
+    assert x.dtype == torch.float32 and w.dtype == torch.float32 and y.dtype == torch.float32
+    assert x.stride(1) == 1 and y.stride(1) == 1 and w.is_contiguous()
+    B, K = x.shape
+    N = w.shape[0]
+    _check(load_library().dfd_linear_rows(_ptr(x), x.stride(0), _ptr(w), _ptr(bias), _ptr(y), y.stride(0), epilogue, B, N, K,
+                                          _stream()), "dfd_linear_rows")
+    return y
+
+
+def decoder_attn_workspace_bytes(B, heads, d, splits):
+    return load_library().dfd_decoder_attn_workspace(B, heads, d, splits)
+
+
+def decoder_attn_fwd(q, k, v, frame_mask, mix, stats, workspace, splits, B, T, patches, heads, d=64):
+    _dev(q, k, v, frame_mask, mix, stats, workspace)
+    assert q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    assert frame_mask.dtype == torch.uint8 and frame_mask.is_contiguous()
+    _check(load_library().dfd_decoder_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _DTYPE[k.dtype], _ptr(frame_mask), _ptr(mix),
+                                               _ptr(stats), _ptr(workspace), splits, B, T, patches, heads, d, _stream()),
+           "dfd_decoder_attn_fwd")
+    return mix
+
+
+def head_fwd(x, gamma, beta, proj, feat, raw, logits, eps=1e-5):
+    _dev(x, gamma, beta, proj, feat, raw, logits)
+    B, D = x.shape
+    assert proj.is_contiguous() and proj.shape[0] == D
+    _check(load_library().dfd_head_fwd(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(proj), _ptr(feat), _ptr(raw),
+                                       _ptr(logits), B, D, proj.shape[1], eps, _stream()), "dfd_head_fwd")
+    return logits

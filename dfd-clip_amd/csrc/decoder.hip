@@ -1,0 +1,337 @@
+// Temporal decoder forward kernels (reference src/models.py:99-146, :160-176, :323-361, :551-553).
+//
+// The decoder has ONE query token per clip, so everything except the K/V pass is a handful of
+// [B, D] row operations streaming ~6.5 M fp32 weights per block; the K/V pass is a pure HBM
+// stream: per clip and layer 2·S·D·sizeof(kv) bytes, read exactly once.
+//
+// dfd_decoder_attn_fwd — single-query two-branch attention.  K/V rows are [heads*64] wide.
+//   A row is covered by heads*8 threads, 8 channels (16 B of bf16 / 32 B of f32) each, so a
+//   head's three reductions (q_s·k, q_c·k, ‖q_c−k‖₁) are 3-step xor-shuffles inside 8-lane
+//   groups.  R rows are processed side by side per workgroup; each thread keeps an online
+//   softmax state (max, sum, acc_s[8]) and the CoDA accumulator acc_c[8] for its channels.
+//   Workgroups split S; partial states are merged by decoder_attn_combine_kernel, which also
+//   emits (max, sumexp) per (clip, head) for the backward pass.
+// dfd_linear_rows — y[B,N] = x[B,K]·W[N,K]ᵀ + b: one wave per output column streams the weight
+//   row once per 8 clips; x stays L1/L2 resident.
+// dfd_head_fwd — ln_post + projection + 5·z/(‖z‖+1e-10).
+#include "common.hpp"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int PART = 2 + 2 * HD;  // floats per (clip, split, head): m, l, acc_s[64], acc_c[64]
+
+template <typename T> struct Ld8;
+template <> struct Ld8<float> {
+  static __device__ __forceinline__ void load(const float* p, float* o) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+  }
+};
+template <> struct Ld8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float* o) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)a[e];
+  }
+};
+
+__device__ __forceinline__ float group8_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+
+__device__ __forceinline__ float fast_tanh(float x) {
+  // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, abs error ~1e-7 around 0
+  const float e = __expf(2.0f * x);
+  return 1.0f - 2.0f / (e + 1.0f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void decoder_attn_partial_kernel(const float* __restrict__ q, const T* __restrict__ k,
+                                                                    const T* __restrict__ v,
+                                                                    const uint8_t* __restrict__ frame_mask,
+                                                                    float* __restrict__ ws, int splits, int T_frames,
+                                                                    int patches, int heads, int R) {
+  extern __shared__ float red[];  // [R][tpr][18]
+  const int tpr = heads * 8;
+  const int b = blockIdx.y, split = blockIdx.x;
+  const int rs = threadIdx.x / tpr, tr = threadIdx.x % tpr;
+  const int hd = tr >> 3, sub = tr & 7;
+  const int S = T_frames * patches;
+  const int D = heads * HD;
+  const int per = (S + splits - 1) / splits;
+  const int s_begin = split * per;
+  const int s_end = min(S, s_begin + per);
+
+  float qs[8], qc[8];
+  {
+    const float* qp = q + ((int64_t)b * heads + hd) * (2 * HD) + sub * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      qs[e] = qp[e] * 0.125f;
+      qc[e] = qp[HD + e];
+    }
+  }
+  float mx = -INFINITY, l = 0.f, as[8], ac[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { as[e] = 0.f; ac[e] = 0.f; }
+
+  const T* kb = k + (int64_t)b * S * D + hd * HD + sub * 8;
+  const T* vb = v + (int64_t)b * S * D + hd * HD + sub * 8;
+  const uint8_t* mb = frame_mask + (int64_t)b * T_frames;
+  // every lane of an 8-lane group walks the same rows, so the shuffles below are convergent
+  for (int s = s_begin + rs; s < s_end; s += R) {
+    float kk[8], vv[8];
+    Ld8<T>::load(kb + (int64_t)s * D, kk);
+    Ld8<T>::load(vb + (int64_t)s * D, vv);
+    float ds = 0.f, dc = 0.f, l1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ds = fmaf(qs[e], kk[e], ds);
+      dc = fmaf(qc[e] * 0.125f, kk[e], dc);
+      l1 += fabsf(qc[e] - kk[e]);
+    }
+    ds = group8_sum(ds);
+    dc = group8_sum(dc);
+    l1 = group8_sum(l1);
+    if (mb[s / patches]) {
+      if (ds > mx) {
+        const float alpha = __expf(mx - ds);
+        l *= alpha;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) as[e] *= alpha;
+        mx = ds;
+      }
+      const float p = __expf(ds - mx);
+      l += p;
+      const float gate = 2.0f / (1.0f + __expf(l1 * 0.125f));  // 2·sigmoid(−l1/√d)
+      const float c = fast_tanh(dc) * gate;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        as[e] = fmaf(p, vv[e], as[e]);
+        ac[e] = fmaf(c, vv[e], ac[e]);
+      }
+    }
+  }
+  // merge the R row slots through LDS
+  float* mine = red + ((size_t)rs * tpr + tr) * 18;
+  mine[0] = mx;
+  mine[1] = l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { mine[2 + e] = as[e]; mine[10 + e] = ac[e]; }
+  __syncthreads();
+  if (rs == 0) {
+    float M = mx;
+    for (int r2 = 1; r2 < R; ++r2) M = fmaxf(M, red[((size_t)r2 * tpr + tr) * 18]);
+    float L = 0.f, As[8], Ac[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { As[e] = 0.f; Ac[e] = 0.f; }
+    for (int r2 = 0; r2 < R; ++r2) {
+      const float* o = red + ((size_t)r2 * tpr + tr) * 18;
+      const float w = (o[0] == -INFINITY) ? 0.f : __expf(o[0] - M);
+      L = fmaf(o[1], w, L);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { As[e] = fmaf(o[2 + e], w, As[e]); Ac[e] += o[10 + e]; }
+    }
+    float* dst = ws + (((int64_t)b * splits + split) * heads + hd) * PART;
+    if (sub == 0) { dst[0] = M; dst[1] = L; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dst[2 + sub * 8 + e] = As[e]; dst[2 + HD + sub * 8 + e] = Ac[e]; }
+  }
+}
+
+__global__ void decoder_attn_combine_kernel(const float* __restrict__ ws, float* __restrict__ mix,
+                                            float* __restrict__ stats, int splits, int heads) {
+  const int b = blockIdx.x;
+  const int hd = threadIdx.x / HD, c = threadIdx.x % HD;
+  const float* base = ws + ((int64_t)b * splits * heads + hd) * PART;
+  float M = -INFINITY;
+  for (int s = 0; s < splits; ++s) M = fmaxf(M, base[(int64_t)s * heads * PART]);
+  float L = 0.f, As = 0.f, Ac = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    const float* o = base + (int64_t)s * heads * PART;
+    const float w = (o[0] == -INFINITY) ? 0.f : __expf(o[0] - M);
+    L = fmaf(o[1], w, L);
+    As = fmaf(o[2 + c], w, As);
+    Ac += o[2 + HD + c];
+  }
+  // (softmax branch + CoDA branch) / n_act, n_act = 2 (models.py:140-142).  All keys masked:
+  // L == 0 -> NaN, as the reference's softmax over all -inf.
+  mix[(int64_t)b * heads * HD + threadIdx.x] = 0.5f * (As / L) + 0.5f * Ac;
+  if (c == 0) {
+    stats[((int64_t)b * heads + hd) * 2 + 0] = M;
+    stats[((int64_t)b * heads + hd) * 2 + 1] = L;
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          const float* __restrict__ W, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int64_t ldy, int B, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* wr = W + (int64_t)n * K;
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int kk = lane * 4; kk < K; kk += 256) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + kk);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (b0 + i < B) {
+          const f32x4 x4 = *reinterpret_cast<const f32x4*>(x + (int64_t)(b0 + i) * ldx + kk);
+          acc[i] = fmaf(w4[0], x4[0], fmaf(w4[1], x4[1], fmaf(w4[2], x4[2], fmaf(w4[3], x4[3], acc[i]))));
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane < 8 && b0 + lane < B) {
+      float r = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r = (lane == i) ? acc[i] : r;
+      r += bias ? bias[n] : 0.f;
+      float* yp = y + (int64_t)(b0 + lane) * ldy + n;
+      if constexpr (EPI == DFD_EPI_BIAS) *yp = r;
+      else if constexpr (EPI == DFD_EPI_BIAS_QUICKGELU) *yp = quick_gelu(r);
+      else *yp = *yp + r;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const float* __restrict__ proj,
+                                                   float* __restrict__ feat, float* __restrict__ raw,
+                                                   float* __restrict__ logits, int D, int out_dim, float eps) {
+  extern __shared__ float sh[];  // [D] feature, [out_dim] z, [8] scratch
+  float* f = sh;
+  float* z = sh + D;
+  float* scratch = z + out_dim;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xr = x + (int64_t)b * ldx;
+  float s = 0.f;
+  for (int c = tid; c < D; c += 256) s += xr[c];
+  s = wave_sum(s);
+  if (lane == 0) scratch[wave] = s;
+  __syncthreads();
+  const float mean = (scratch[0] + scratch[1] + scratch[2] + scratch[3]) / (float)D;
+  __syncthreads();
+  float qv = 0.f;
+  for (int c = tid; c < D; c += 256) { const float d = xr[c] - mean; qv += d * d; }
+  qv = wave_sum(qv);
+  if (lane == 0) scratch[wave] = qv;
+  __syncthreads();
+  const float rstd = rsqrtf((scratch[0] + scratch[1] + scratch[2] + scratch[3]) / (float)D + eps);
+  for (int c = tid; c < D; c += 256) {
+    const float o = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+    f[c] = o;
+    feat[(int64_t)b * D + c] = o;
+  }
+  __syncthreads();
+  for (int o = wave; o < out_dim; o += 4) {
+    float a = 0.f;
+    for (int c = lane; c < D; c += 64) a = fmaf(f[c], proj[(int64_t)c * out_dim + o], a);
+    a = wave_sum(a);
+    if (lane == 0) z[o] = a;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float n2 = 0.f;
+    for (int o = lane; o < out_dim; o += 64) n2 += z[o] * z[o];
+    n2 = wave_sum(n2);
+    const float inv = 5.0f / (sqrtf(n2) + 1e-10f);
+    for (int o = lane; o < out_dim; o += 64) {
+      raw[(int64_t)b * out_dim + o] = z[o];
+      logits[(int64_t)b * out_dim + o] = z[o] * inv;
+    }
+  }
+}
+
+int rows_per_block(int heads) {
+  const int tpr = heads * 8;
+  int R = (256 + tpr - 1) / tpr;
+  while ((tpr * R) % 64 != 0) ++R;
+  return R;
+}
+
+}  // namespace
+
+extern "C" size_t dfd_decoder_attn_workspace(int B, int heads, int d, int splits) {
+  if (B <= 0 || heads <= 0 || splits <= 0 || d != HD) return 0;
+  return (size_t)B * splits * heads * PART * sizeof(float);
+}
+
+extern "C" int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v, int kv_dtype,
+                                    const uint8_t* frame_mask, float* mix, float* stats, void* workspace, int splits,
+                                    int B, int T, int patches, int heads, int d, void* stream) {
+  DFD_REQUIRE(q && k && v && frame_mask && mix && stats && workspace, "dfd_decoder_attn_fwd: null pointer");
+  DFD_REQUIRE(d == HD, "dfd_decoder_attn_fwd: head dim %d, only 64 is supported", d);
+  DFD_REQUIRE(B >= 0 && T > 0 && patches > 0 && heads > 0 && heads * HD <= 1024, "dfd_decoder_attn_fwd: bad shape");
+  DFD_REQUIRE(splits > 0 && splits <= 4096, "dfd_decoder_attn_fwd: splits=%d", splits);
+  DFD_REQUIRE(kv_dtype == DFD_F32 || kv_dtype == DFD_BF16, "dfd_decoder_attn_fwd: kv_dtype=%d", kv_dtype);
+  DFD_REQUIRE(dfd_aligned16(k) && dfd_aligned16(v) && dfd_aligned16(q), "dfd_decoder_attn_fwd: pointers must be 16-byte aligned");
+  if (B == 0) return DFD_OK;
+  const int R = rows_per_block(heads);
+  const int threads = heads * 8 * R;
+  DFD_REQUIRE(threads <= 1024, "dfd_decoder_attn_fwd: heads=%d needs %d threads", heads, threads);
+  const size_t lds = (size_t)threads * 18 * sizeof(float);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(splits, B), block(threads);
+  float* ws = static_cast<float*>(workspace);
+  if (kv_dtype == DFD_F32)
+    hipLaunchKernelGGL((decoder_attn_partial_kernel<float>), grid, block, lds, st, q, static_cast<const float*>(k),
+                       static_cast<const float*>(v), frame_mask, ws, splits, T, patches, heads, R);
+  else
+    hipLaunchKernelGGL((decoder_attn_partial_kernel<bf16_t>), grid, block, lds, st, q, static_cast<const bf16_t*>(k),
+                       static_cast<const bf16_t*>(v), frame_mask, ws, splits, T, patches, heads, R);
+  DFD_CHECK_LAUNCH("dfd_decoder_attn_fwd(partial)");
+  hipLaunchKernelGGL(decoder_attn_combine_kernel, dim3(B), dim3(heads * HD), 0, st, ws, mix, stats, splits, heads);
+  DFD_CHECK_LAUNCH("dfd_decoder_attn_fwd(combine)");
+  return DFD_OK;
+}
+
+extern "C" int dfd_linear_rows(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t ldy,
+                               int epilogue, int B, int N, int K, void* stream) {
+  DFD_REQUIRE(x && W && y, "dfd_linear_rows: null pointer");
+  DFD_REQUIRE(B >= 0 && B <= 64 && N > 0 && K > 0 && K % 4 == 0, "dfd_linear_rows: bad shape B=%d N=%d K=%d", B, N, K);
+  DFD_REQUIRE(ldx >= K && ldx % 4 == 0 && ldy >= N, "dfd_linear_rows: bad leading dimensions");
+  DFD_REQUIRE(dfd_aligned16(x) && dfd_aligned16(W), "dfd_linear_rows: x and W must be 16-byte aligned");
+  if (B == 0) return DFD_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((N + 3) / 4), block(256);
+  switch (epilogue) {
+    case DFD_EPI_BIAS:
+      hipLaunchKernelGGL((linear_rows_kernel<DFD_EPI_BIAS>), grid, block, 0, st, x, ldx, W, bias, y, ldy, B, N, K);
+      break;
+    case DFD_EPI_BIAS_QUICKGELU:
+      hipLaunchKernelGGL((linear_rows_kernel<DFD_EPI_BIAS_QUICKGELU>), grid, block, 0, st, x, ldx, W, bias, y, ldy, B, N, K);
+      break;
+    case DFD_EPI_BIAS_RESIDUAL:
+      hipLaunchKernelGGL((linear_rows_kernel<DFD_EPI_BIAS_RESIDUAL>), grid, block, 0, st, x, ldx, W, bias, y, ldy, B, N, K);
+      break;
+    default:
+      dfd_set_error("dfd_linear_rows: epilogue %d unsupported", epilogue);
+      return DFD_ERR_INVALID_ARG;
+  }
+  DFD_CHECK_LAUNCH("dfd_linear_rows");
+  return DFD_OK;
+}
+
+extern "C" int dfd_head_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* proj,
+                            float* video_feature, float* raw_logits, float* logits, int B, int D, int out_dim,
+                            float eps, void* stream) {
+  DFD_REQUIRE(x && gamma && beta && proj && video_feature && raw_logits && logits, "dfd_head_fwd: null pointer");
+  DFD_REQUIRE(B >= 0 && D > 0 && out_dim > 0 && out_dim <= 4096 && ldx >= D, "dfd_head_fwd: bad shape");
+  if (B == 0) return DFD_OK;
+  const size_t lds = (size_t)(D + out_dim + 8) * sizeof(float);
+  hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), x, ldx, gamma, beta, proj,
+                     video_feature, raw_logits, logits, D, out_dim, eps);
+  DFD_CHECK_LAUNCH("dfd_head_fwd");
+  return DFD_OK;
+}

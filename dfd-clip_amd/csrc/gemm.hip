@@ -1,0 +1,260 @@
+// C = epilogue(A[M,K] · W[N,K]ᵀ) on the gfx950 matrix cores — the encoder's four GEMM shapes
+// (QKV, out_proj, c_fc, c_proj; reference clip/model.py:186, :197, :208-212) plus the patch
+// conv as a GEMM (clip/model.py:277).
+//
+// gemm128: general-shape kernel.  128x128 output tile per 256-thread workgroup (4 waves as
+//   2x2, each wave a 64x64 patch = 2x2 MFMA 32x32 tiles), K consumed 64 BYTES per row per step
+//   (32 bf16 / 16 f32), LDS rows padded to 80 B, double-buffered LDS with the next tile's
+//   global loads in flight across the MFMA block.  bf16 operands use v_mfma_f32_32x32x16_bf16;
+//   f32 operands use v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain — the 1e-3 parity path).
+//   Any M, N; K % 32 == 0.  Out-of-range rows load zeros and are not stored.
+//
+// Both A and W are K-contiguous, so both MFMA operands are plain 16-byte row reads: lane
+// (r = lane&31, h = lane>>5) holds A[row r][k-slice h] and W[row r][k-slice h].
+#include "common.hpp"
+
+struct GemmArgs {
+  const void* A;
+  const void* W;
+  void* C;
+  const float* bias;
+  const float* pos;
+  const float* cls;
+  void* k_export;
+  void* v_export;
+  int64_t lda, ldw, ldc, M;
+  int N, K, tokens, frames_per_clip;
+};
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROW_BYTES = 64;   // K bytes per row per step
+constexpr int ROW_STRIDE = 80;  // padded LDS row
+constexpr int TILE_BYTES = BM * ROW_STRIDE;
+
+template <typename CT> __device__ __forceinline__ void store_c(void* C, int64_t off, float v) {
+  static_cast<CT*>(C)[off] = from_f32<CT>(v);
+}
+
+template <typename CT, int EPI>
+__device__ __forceinline__ void epilogue_elem(const GemmArgs& a, int64_t m, int n, float acc) {
+  if (m >= a.M || n >= a.N) return;
+  if constexpr (EPI == DFD_EPI_BIAS) {
+    store_c<CT>(a.C, m * a.ldc + n, acc + (a.bias ? a.bias[n] : 0.f));
+  } else if constexpr (EPI == DFD_EPI_BIAS_QUICKGELU) {
+    store_c<CT>(a.C, m * a.ldc + n, quick_gelu(acc + (a.bias ? a.bias[n] : 0.f)));
+  } else if constexpr (EPI == DFD_EPI_BIAS_RESIDUAL) {
+    float* c = static_cast<float*>(a.C) + m * a.ldc + n;
+    *c = *c + (acc + (a.bias ? a.bias[n] : 0.f));
+  } else if constexpr (EPI == DFD_EPI_PATCH_EMBED) {
+    const int P = a.tokens - 1;
+    const int64_t frame = m / P;
+    const int p = (int)(m - frame * P);
+    float* c = static_cast<float*>(a.C);
+    c[(frame * a.tokens + 1 + p) * a.ldc + n] = acc + a.pos[(int64_t)(1 + p) * a.N + n];
+    if (p == 0) c[(frame * a.tokens) * a.ldc + n] = a.cls[n] + a.pos[n];
+  } else if constexpr (EPI == DFD_EPI_QKV_EXPORT) {
+    const float v = acc + (a.bias ? a.bias[n] : 0.f);
+    store_c<CT>(a.C, m * a.ldc + n, v);
+    const int D = a.N / 3;
+    if (a.k_export != nullptr && n >= D) {
+      const int64_t frame = m / a.tokens;
+      const int tok = (int)(m - frame * a.tokens);
+      if (tok > 0) {
+        const bool is_v = n >= 2 * D;
+        const int cc = n - (is_v ? 2 * D : D);
+        const float e = v + (a.pos ? a.pos[(frame % a.frames_per_clip) * D + cc] : 0.f);
+        store_c<CT>(is_v ? a.v_export : a.k_export, (frame * (a.tokens - 1) + tok - 1) * D + cc, e);
+      }
+    }
+  }
+}
+
+template <typename T, typename CT, int EPI>
+__global__ __launch_bounds__(256) void gemm128_kernel(const GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // A0 A1 B0 B1
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+  constexpr int KSTEP = ROW_BYTES / (int)sizeof(T);  // elements of K per step
+  const int nk = a.K / KSTEP;
+
+  // staging assignment: 512 16-byte chunks per matrix tile, 2 per thread
+  const unsigned char* Ab = static_cast<const unsigned char*>(a.A);
+  const unsigned char* Wb = static_cast<const unsigned char*>(a.W);
+  uint4 ra[2], rb[2];
+  int srow[2], scol[2];
+  bool va[2], vb[2];
+  const unsigned char* pa[2];
+  const unsigned char* pb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    srow[i] = c >> 2;
+    scol[i] = (c & 3) * 16;
+    va[i] = (m0 + srow[i]) < a.M;
+    vb[i] = (n0 + srow[i]) < a.N;
+    pa[i] = Ab + ((m0 + srow[i]) * a.lda) * (int64_t)sizeof(T) + scol[i];
+    pb[i] = Wb + ((int64_t)(n0 + srow[i]) * a.ldw) * (int64_t)sizeof(T) + scol[i];
+  }
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i] = va[i] ? *reinterpret_cast<const uint4*>(pa[i] + (int64_t)kt * ROW_BYTES) : uint4{0, 0, 0, 0};
+      rb[i] = vb[i] ? *reinterpret_cast<const uint4*>(pb[i] + (int64_t)kt * ROW_BYTES) : uint4{0, 0, 0, 0};
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<uint4*>(smem + buf * TILE_BYTES + srow[i] * ROW_STRIDE + scol[i]) = ra[i];
+      *reinterpret_cast<uint4*>(smem + (2 + buf) * TILE_BYTES + srow[i] * ROW_STRIDE + scol[i]) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const unsigned char* As = smem + buf * TILE_BYTES + (wm * 64 + r) * ROW_STRIDE;
+    const unsigned char* Bs = smem + (2 + buf) * TILE_BYTES + (wn * 64 + r) * ROW_STRIDE;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROW_STRIDE + s * 32 + h * 16);
+          fb[i] = *reinterpret_cast<const bf16x8*>(Bs + i * 32 * ROW_STRIDE + s * 32 + h * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // f32: lane half h owns k-slice [8h, 8h+8) of the 16-wide step; MFMA step s pairs k = s and
+      // k = 8 + s (any pairing is valid as long as A and W use the same one).
+      f32x4 fa[2][2], fb[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          fa[i][q] = *reinterpret_cast<const f32x4*>(As + i * 32 * ROW_STRIDE + h * 32 + q * 16);
+          fb[i][q] = *reinterpret_cast<const f32x4*>(Bs + i * 32 * ROW_STRIDE + h * 32 + q * 16);
+        }
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s >> 2][s & 3], fb[j][s >> 2][s & 3], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int n = n0 + wn * 64 + j * 32 + r;
+        epilogue_elem<CT, EPI>(a, m, n, acc[i][j][e]);
+      }
+}
+
+template <typename T, typename CT>
+int launch_gemm128(const GemmArgs& a, int epi, hipStream_t st) {
+  const dim3 grid((a.N + BN - 1) / BN, (unsigned)((a.M + BM - 1) / BM)), block(256);
+#define EPI_CASE(E)                                                                    \
+  case E:                                                                              \
+    hipLaunchKernelGGL((gemm128_kernel<T, CT, E>), grid, block, 0, st, a);             \
+    break;
+  switch (epi) {
+    EPI_CASE(DFD_EPI_BIAS)
+    EPI_CASE(DFD_EPI_BIAS_QUICKGELU)
+    EPI_CASE(DFD_EPI_QKV_EXPORT)
+    default:
+      if constexpr (sizeof(CT) == 4) {
+        switch (epi) {
+          EPI_CASE(DFD_EPI_BIAS_RESIDUAL)
+          EPI_CASE(DFD_EPI_PATCH_EMBED)
+          default:
+            dfd_set_error("dfd_gemm: unknown epilogue %d", epi);
+            return DFD_ERR_INVALID_ARG;
+        }
+      } else {
+        dfd_set_error("dfd_gemm: epilogue %d needs an f32 C", epi);
+        return DFD_ERR_INVALID_ARG;
+      }
+  }
+#undef EPI_CASE
+  DFD_CHECK_LAUNCH("dfd_gemm");
+  return DFD_OK;
+}
+
+}  // namespace
+
+// tuned bf16 kernel (gemm256.hip); returns 1 when the shape is not eligible
+int dfd_gemm256_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st);
+
+extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int ab_dtype, void* C, int64_t ldc,
+                        int c_dtype, const float* bias, int epilogue, const dfd_gemm_extra* extra, int64_t M, int N,
+                        int K, void* stream) {
+  DFD_REQUIRE(A && W && C, "dfd_gemm: null pointer");
+  DFD_REQUIRE(M >= 0 && N > 0 && K > 0, "dfd_gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+  DFD_REQUIRE(ab_dtype == DFD_F32 || ab_dtype == DFD_BF16, "dfd_gemm: ab_dtype=%d", ab_dtype);
+  DFD_REQUIRE(c_dtype == DFD_F32 || c_dtype == DFD_BF16, "dfd_gemm: c_dtype=%d", c_dtype);
+  DFD_REQUIRE(!(ab_dtype == DFD_F32 && c_dtype == DFD_BF16), "dfd_gemm: f32 operands with bf16 output unsupported");
+  DFD_REQUIRE(K % 32 == 0, "dfd_gemm: K=%d must be a multiple of 32", K);
+  const int esz = ab_dtype == DFD_F32 ? 4 : 2;
+  DFD_REQUIRE(lda >= K && ldw >= K && (lda * esz) % 16 == 0 && (ldw * esz) % 16 == 0, "dfd_gemm: lda=%lld ldw=%lld must be >= K and 16-byte multiples", (long long)lda, (long long)ldw);
+  DFD_REQUIRE(dfd_aligned16(A) && dfd_aligned16(W), "dfd_gemm: A and W must be 16-byte aligned");
+  GemmArgs a{};
+  a.A = A; a.W = W; a.C = C; a.bias = bias;
+  a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  if (epilogue == DFD_EPI_PATCH_EMBED) {
+    DFD_REQUIRE(extra && extra->pos && extra->cls && extra->tokens > 1, "dfd_gemm: PATCH_EMBED needs extra.pos, extra.cls, extra.tokens");
+    DFD_REQUIRE(M % (extra->tokens - 1) == 0, "dfd_gemm: PATCH_EMBED M=%lld is not a whole number of frames", (long long)M);
+    DFD_REQUIRE(c_dtype == DFD_F32 && ldc >= N, "dfd_gemm: PATCH_EMBED writes an f32 token matrix");
+  } else {
+    DFD_REQUIRE(ldc >= N, "dfd_gemm: ldc=%lld < N", (long long)ldc);
+  }
+  if (epilogue == DFD_EPI_QKV_EXPORT) {
+    DFD_REQUIRE(extra && extra->tokens > 1 && N % 3 == 0, "dfd_gemm: QKV_EXPORT needs extra.tokens and N %% 3 == 0");
+    DFD_REQUIRE(M % extra->tokens == 0, "dfd_gemm: QKV_EXPORT M=%lld is not a whole number of frames", (long long)M);
+    DFD_REQUIRE(!extra->k_export == !extra->v_export, "dfd_gemm: QKV_EXPORT needs both k_export and v_export or neither");
+    DFD_REQUIRE(!extra->pos || extra->frames_per_clip > 0, "dfd_gemm: QKV_EXPORT with pos needs frames_per_clip");
+  }
+  if (extra) {
+    a.pos = extra->pos; a.cls = extra->cls; a.k_export = extra->k_export; a.v_export = extra->v_export;
+    a.tokens = extra->tokens; a.frames_per_clip = extra->frames_per_clip > 0 ? extra->frames_per_clip : 1;
+  }
+  if (M == 0) return DFD_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (ab_dtype == DFD_BF16) {
+    const int rc = dfd_gemm256_try(a, c_dtype, epilogue, st);
+    if (rc <= 0) return rc;
+  }
+  if (ab_dtype == DFD_F32) return launch_gemm128<float, float>(a, epilogue, st);
+  if (c_dtype == DFD_BF16) return launch_gemm128<bf16_t, bf16_t>(a, epilogue, st);
+  return launch_gemm128<bf16_t, float>(a, epilogue, st);
+}

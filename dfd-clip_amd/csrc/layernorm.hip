@@ -1,0 +1,165 @@
+// LayerNorm (fp32 statistics) and patchify — the HBM-bound row kernels of the encoder.
+//
+// dfd_layernorm: one 64-lane wave per row; the row lives in registers (float4 per lane per
+//   256-column slab), so x is read once and y written once: algorithmic bytes per row =
+//   cols * (4 + sizeof(y)).  Two-pass statistics in registers (mean, then centred sum of
+//   squares), biased variance, eps inside the sqrt: the reference's nn.LayerNorm on fp32
+//   (clip/model.py:157-163).
+// dfd_patchify: frames [N,3,R,R] f32 -> patch rows [N*P, kpad] so that the patch conv
+//   (clip/model.py:264, :277) is a plain A·Wᵀ GEMM with W = conv1.weight.view(D, 3*p*p).
+#include "common.hpp"
+
+template <typename OutT, int SLABS>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, OutT* __restrict__ y,
+                                                             int64_t ldy, int64_t rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  f32x4 v[SLABS];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < SLABS; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < cols) {
+      v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    } else {
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < SLABS; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < cols) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[i][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+  OutT* yr = y + row * ldy;
+#pragma unroll
+  for (int i = 0; i < SLABS; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < cols) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+      if constexpr (sizeof(OutT) == 4) {
+        *reinterpret_cast<f32x4*>(yr + c) = o;
+      } else {
+        bf16x4 ob;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)o[j];
+        *reinterpret_cast<bf16x4*>(yr + c) = ob;
+      }
+    }
+  }
+}
+
+template <typename OutT>
+static int launch_ln(const float* x, int64_t ldx, const float* g, const float* b, void* y, int64_t ldy, int64_t rows,
+                     int cols, float eps, hipStream_t st) {
+  const int slabs = (cols + 255) / 256;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  OutT* yo = static_cast<OutT*>(y);
+#define LN_CASE(S)                                                                                     \
+  case S:                                                                                              \
+    hipLaunchKernelGGL((layernorm_rows_kernel<OutT, S>), grid, block, 0, st, x, ldx, g, b, yo, ldy, rows, cols, eps); \
+    break;
+  switch (slabs) {
+    LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+    LN_CASE(9) LN_CASE(10) LN_CASE(11) LN_CASE(12) LN_CASE(13) LN_CASE(14) LN_CASE(15) LN_CASE(16)
+    default:
+      dfd_set_error("dfd_layernorm: cols=%d > 4096 unsupported", cols);
+      return DFD_ERR_INVALID_ARG;
+  }
+#undef LN_CASE
+  DFD_CHECK_LAUNCH("dfd_layernorm");
+  return DFD_OK;
+}
+
+extern "C" int dfd_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+                             int y_dtype, int64_t rows, int cols, float eps, void* stream) {
+  DFD_REQUIRE(x && gamma && beta && y, "dfd_layernorm: null pointer");
+  DFD_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= 4096, "dfd_layernorm: cols=%d must be a multiple of 4, <= 4096", cols);
+  DFD_REQUIRE(ldx >= cols && ldy >= cols && ldx % 4 == 0 && ldy % 4 == 0, "dfd_layernorm: bad leading dimension (ldx=%lld ldy=%lld)", (long long)ldx, (long long)ldy);
+  DFD_REQUIRE(dfd_aligned16(x) && dfd_aligned16(gamma) && dfd_aligned16(beta) && ((uintptr_t)y & 7) == 0, "dfd_layernorm: pointers must be 16-byte aligned");
+  DFD_REQUIRE(y_dtype == DFD_F32 || y_dtype == DFD_BF16, "dfd_layernorm: y_dtype=%d", y_dtype);
+  if (rows == 0) return DFD_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (y_dtype == DFD_F32) return launch_ln<float>(x, ldx, gamma, beta, y, ldy, rows, cols, eps, st);
+  return launch_ln<bf16_t>(x, ldx, gamma, beta, y, ldy, rows, cols, eps, st);
+}
+
+// ---- patchify -----------------------------------------------------------------------------
+// One thread per 4 consecutive output columns of one patch row.  Output column
+// k = c*p*p + i*p + j reads frame pixel (c, gy*p + i, gx*p + j).  Reads are contiguous along j
+// (p pixels = 64 B for p=16), writes fully coalesced.
+template <typename OutT>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ frames, OutT* __restrict__ out,
+                                                       int n_frames, int res, int patch, int kpad) {
+  const int grid_w = res / patch;
+  const int P = grid_w * grid_w;
+  const int kq = kpad >> 2;  // column quads per row
+  const int64_t total = (int64_t)n_frames * P * kq;
+  const int kreal = 3 * patch * patch;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % kq);
+    const int64_t row = idx / kq;
+    const int p = (int)(row % P);
+    const int n = (int)(row / P);
+    const int gy = p / grid_w, gx = p % grid_w;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = q * 4 + e;
+      if (k < kreal) {
+        const int c = k / (patch * patch);
+        const int r = k % (patch * patch);
+        const int i = r / patch, j = r % patch;
+        v[e] = frames[(((int64_t)n * 3 + c) * res + (gy * patch + i)) * res + gx * patch + j];
+      } else {
+        v[e] = 0.f;
+      }
+    }
+    OutT* o = out + row * kpad + q * 4;
+    if constexpr (sizeof(OutT) == 4) {
+      *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+      bf16x4 ob;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ob[e] = (bf16_t)v[e];
+      *reinterpret_cast<bf16x4*>(o) = ob;
+    }
+  }
+}
+
+extern "C" int dfd_patchify(const float* frames, void* patches, int out_dtype, int n_frames, int res, int patch,
+                            int kpad, void* stream) {
+  DFD_REQUIRE(frames && patches, "dfd_patchify: null pointer");
+  DFD_REQUIRE(n_frames >= 0 && res > 0 && patch > 0 && res % patch == 0, "dfd_patchify: res=%d patch=%d", res, patch);
+  DFD_REQUIRE(kpad % 4 == 0 && kpad >= 3 * patch * patch, "dfd_patchify: kpad=%d too small or not a multiple of 4", kpad);
+  DFD_REQUIRE(out_dtype == DFD_F32 || out_dtype == DFD_BF16, "dfd_patchify: out_dtype=%d", out_dtype);
+  DFD_REQUIRE(dfd_aligned16(patches), "dfd_patchify: output must be 16-byte aligned");
+  if (n_frames == 0) return DFD_OK;
+  const int P = (res / patch) * (res / patch);
+  const int64_t total = (int64_t)n_frames * P * (kpad / 4);
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (out_dtype == DFD_F32)
+    hipLaunchKernelGGL((patchify_kernel<float>), dim3(blocks), dim3(256), 0, st, frames, static_cast<float*>(patches), n_frames, res, patch, kpad);
+  else
+    hipLaunchKernelGGL((patchify_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, frames, static_cast<bf16_t*>(patches), n_frames, res, patch, kpad);
+  DFD_CHECK_LAUNCH("dfd_patchify");
+  return DFD_OK;
+}

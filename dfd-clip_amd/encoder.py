@@ -1,0 +1,261 @@
+"""CLIP visual encoder that exports per-layer attention keys/values, on HIP kernels.
+
+Host-side mirror of the reference's modified `VisionTransformer` (reference
+`src/clip/model.py:254-294`; blocks `:202-226`; attention `:171-199`; stack `:229-251`): same
+constructor, attributes, parameter names (so reference checkpoints load unchanged) and the
+same `forward(x, with_out, with_q)` result — a list with one dict per block holding
+`k`, `v` `[N, tokens, heads, 64]` (bias included, un-scaled, CLS row kept).  `ln_post` and
+`proj` exist as parameters and, as in the reference, are never applied.
+
+All arithmetic runs in libdfdclip_hip.so.  Two precisions:
+  * "fp32": f32 operands on the exact-f32 matrix cores — the 1e-3 parity path;
+  * "bf16": bf16 GEMM/attention operands, f32 accumulation, f32 residual stream, f32
+    LayerNorm/softmax statistics — the throughput path.
+
+HBM layout for a batch of N frames (M = N*tokens rows, D = width), all row-major:
+  x    [M, D]   f32   residual stream (updated in place by the residual epilogues)
+  h    [M, D]   act   LayerNorm output = GEMM A operand
+  qkv  [M, 3D]  act   q | k | v column blocks, head = 64 contiguous columns
+  mix  [M, D]   act   attention output
+  u    [M, 4D]  act   QuickGELU(c_fc) output
+`extract_kv` additionally writes the decoder's K/V operands straight from the QKV GEMM
+epilogue: `[N*P, D]` per selected layer, CLS row dropped, temporal positional embedding added
+(reference `src/models.py:505-509`, `:326-334`), and skips the work of the last selected
+layer that cannot reach any exported tensor.
+"""
+import torch
+from torch import nn
+
+from . import capi
+
+
+class _Holder(nn.Module):
+    """Parameter container; never called."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder")
+
+
+class _AttnParams(_Holder):
+    def __init__(self, d):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.empty(3 * d))
+        self.out_proj = nn.Linear(d, d)
+        nn.init.normal_(self.in_proj_weight, std=d ** -0.5)
+        nn.init.normal_(self.in_proj_bias, std=0.02)
+
+
+class _Mlp(_Holder):
+    def __init__(self, d):
+        super().__init__()
+        self.c_fc = nn.Linear(d, 4 * d)
+        self.c_proj = nn.Linear(4 * d, d)
+
+
+class ResidualAttentionBlock(_Holder):
+    def __init__(self, d_model, n_head):
+        super().__init__()
+        self.attn = _AttnParams(d_model)
+        self.attn.n_head = n_head
+        self.ln_1 = nn.LayerNorm(d_model)
+        self.mlp = _Mlp(d_model)
+        self.ln_2 = nn.LayerNorm(d_model)
+
+
+class Transformer(_Holder):
+    def __init__(self, width, layers, heads):
+        super().__init__()
+        self.width = width
+        self.layers = layers
+        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads) for _ in range(layers)])
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim, precision="bf16"):
+        super().__init__()
+        assert width % heads == 0 and width // heads == 64, "kernels are built for 64-wide heads"
+        assert precision in ("fp32", "bf16")
+        self.input_resolution = input_resolution
+        self.output_dim = output_dim
+        self.width = width
+        self.layers = layers
+        self.heads = heads
+        self.patch_size = patch_size
+        self.precision = precision
+        self.conv1 = nn.Conv2d(3, width, kernel_size=patch_size, stride=patch_size, bias=False)
+        scale = width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width))
+        self.ln_pre = nn.LayerNorm(width)
+        self.transformer = Transformer(width, layers, heads)
+        self.ln_post = nn.LayerNorm(width)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+        self._prepared = None
+        self._ws = {}
+        self.frame_chunk = 0  # 0 = whole batch in one pass
+
+    # ---- derived device-side operands ---------------------------------------------------
+    @property
+    def tokens(self):
+        return (self.input_resolution // self.patch_size) ** 2 + 1
+
+    @property
+    def act_dtype(self):
+        return torch.float32 if self.precision == "fp32" else torch.bfloat16
+
+    def invalidate(self):
+        """Call after changing parameters in place (load_state_dict and .to() do it themselves)."""
+        self._prepared = None
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._prepared = None
+        self._ws = {}
+        return out
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self._prepared = None
+        return out
+
+    def _prepare(self):
+        if self._prepared is not None:
+            return self._prepared
+        dev = self.class_embedding.device
+        if dev.type != "cuda":
+            raise capi.DfdError("the encoder runs on HIP kernels only: move the model to a GPU (.to('cuda'))")
+        act = self.act_dtype
+        kreal = 3 * self.patch_size ** 2
+        kpad = (kreal + 31) // 32 * 32
+        wp = torch.zeros(self.width, kpad, device=dev, dtype=torch.float32)
+        wp[:, :kreal] = self.conv1.weight.detach().reshape(self.width, kreal)
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        p = dict(kpad=kpad, w_patch=wp.to(act).contiguous(), cls=f32(self.class_embedding),
+                 pos=f32(self.positional_embedding), ln_pre=(f32(self.ln_pre.weight), f32(self.ln_pre.bias)), blocks=[])
+        for blk in self.transformer.resblocks:
+            p["blocks"].append(dict(
+                ln1=(f32(blk.ln_1.weight), f32(blk.ln_1.bias)), ln2=(f32(blk.ln_2.weight), f32(blk.ln_2.bias)),
+                w_qkv=blk.attn.in_proj_weight.detach().to(act).contiguous(), b_qkv=f32(blk.attn.in_proj_bias),
+                w_out=blk.attn.out_proj.weight.detach().to(act).contiguous(), b_out=f32(blk.attn.out_proj.bias),
+                w_fc=blk.mlp.c_fc.weight.detach().to(act).contiguous(), b_fc=f32(blk.mlp.c_fc.bias),
+                w_proj=blk.mlp.c_proj.weight.detach().to(act).contiguous(), b_proj=f32(blk.mlp.c_proj.bias)))
+        self._prepared = p
+        return p
+
+    def _workspace(self, n, keep_layers):
+        """Activation buffers for n frames.  Rows are padded to a multiple of 256 so tiled kernels
+        never read out of bounds; pad rows hold zeros/garbage that is never stored to real rows."""
+        key = (n, self.precision, keep_layers)
+        ws = self._ws.get(key)
+        if ws is None:
+            dev = self.class_embedding.device
+            act, D = self.act_dtype, self.width
+            M = n * self.tokens
+            Mp = (M + 255) // 256 * 256
+            P = self.tokens - 1
+            Pp = (n * P + 255) // 256 * 256
+            kpad = self._prepare()["kpad"]
+            ws = dict(
+                x=torch.zeros(Mp, D, device=dev, dtype=torch.float32), h=torch.zeros(Mp, D, device=dev, dtype=act),
+                mix=torch.zeros(Mp, D, device=dev, dtype=act), u=torch.zeros(Mp, 4 * D, device=dev, dtype=act),
+                patches=torch.zeros(Pp, kpad, device=dev, dtype=act),
+                qkv=[torch.zeros(Mp, 3 * D, device=dev, dtype=act) for _ in range(keep_layers)])
+            if len(self._ws) > 4:
+                self._ws.clear()
+            self._ws[key] = ws
+        return ws
+
+    # ---- kernels sequence ---------------------------------------------------------------
+    def _embed(self, frames, ws, p):
+        """conv1 as patchify + GEMM, CLS row, + positional embedding, ln_pre (model.py:277-292)."""
+        n = frames.shape[0]
+        P, D = self.tokens - 1, self.width
+        capi.patchify(frames, ws["patches"], self.input_resolution, self.patch_size)
+        capi.gemm(ws["patches"], p["w_patch"], ws["x"], None, capi.EPI_PATCH_EMBED, m=n * P, pos=p["pos"], cls=p["cls"],
+                  tokens=self.tokens)
+        M = n * self.tokens
+        capi.layernorm(ws["x"][:M], p["ln_pre"][0], p["ln_pre"][1], ws["x"][:M])
+
+    def _block(self, ws, bp, qkv, M, n, kv_only=False, export=None):
+        """One residual attention block (model.py:220-226).  `export` = (k_out, v_out, tpos, T)
+        makes the QKV epilogue also write the decoder operands; `kv_only` stops after the
+        projection (nothing after it can reach an exported tensor)."""
+        D = self.width
+        x, h = ws["x"], ws["h"]
+        capi.layernorm(x[:M], bp["ln1"][0], bp["ln1"][1], h[:M])
+        if export is not None:
+            capi.gemm(h, bp["w_qkv"], qkv, bp["b_qkv"], capi.EPI_QKV_EXPORT, m=M, pos=export[2], k_export=export[0],
+                      v_export=export[1], tokens=self.tokens, frames_per_clip=export[3])
+        else:
+            capi.gemm(h, bp["w_qkv"], qkv, bp["b_qkv"], capi.EPI_QKV_EXPORT, m=M, tokens=self.tokens)
+        if kv_only:
+            return
+        capi.attention_fwd(qkv, ws["mix"], n, self.tokens, self.heads)
+        capi.gemm(ws["mix"], bp["w_out"], x, bp["b_out"], capi.EPI_BIAS_RESIDUAL, m=M)
+        capi.layernorm(x[:M], bp["ln2"][0], bp["ln2"][1], h[:M])
+        capi.gemm(h, bp["w_fc"], ws["u"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M)
+        capi.gemm(ws["u"], bp["w_proj"], x, bp["b_proj"], capi.EPI_BIAS_RESIDUAL, m=M)
+
+    @torch.no_grad()
+    def forward(self, x, with_out=False, with_q=False):
+        """Reference API: frames [N,3,R,R] -> list of per-block dicts (k, v[, q][, out])."""
+        if not x.is_cuda:
+            raise capi.DfdError("the encoder runs on HIP kernels only: pass device tensors")
+        p = self._prepare()
+        frames = x.to(torch.float32).contiguous()
+        n = frames.shape[0]
+        D, H, tok = self.width, self.heads, self.tokens
+        M = n * tok
+        ws = self._workspace(n, self.layers)
+        self._embed(frames, ws, p)
+        result = []
+        for l, bp in enumerate(p["blocks"]):
+            qkv = ws["qkv"][l]
+            self._block(ws, bp, qkv, M, n)
+            t = qkv[:M].view(n, tok, 3, H, 64)
+            d = {"k": t[:, :, 1], "v": t[:, :, 2]}
+            if with_q:
+                d["q"] = t[:, :, 0]
+            if with_out:
+                d["out"] = ws["x"][:M].view(n, tok, D).clone()
+            result.append(d)
+        return result
+
+    @torch.no_grad()
+    def extract_kv(self, x, layer_indices, num_frames, temporal_pos=None, out=None):
+        """Fused extraction for the decoder: frames [N,3,R,R] (N = B*T) ->
+        (k, v): two tensors [L, N*P, D] in the activation dtype, one slab per selected layer,
+        rows ordered (clip, frame, patch) — i.e. `[B, T*P, heads, 64]` per layer — with the
+        temporal positional embedding `temporal_pos` [T, D] (f32) added when given."""
+        if not x.is_cuda:
+            raise capi.DfdError("the encoder runs on HIP kernels only: pass device tensors")
+        p = self._prepare()
+        frames = x.to(torch.float32).contiguous()
+        n = frames.shape[0]
+        assert n % num_frames == 0
+        D, tok = self.width, self.tokens
+        P = tok - 1
+        L = len(layer_indices)
+        if out is None:
+            k_out = torch.empty(L, n * P, D, device=frames.device, dtype=self.act_dtype)
+            v_out = torch.empty_like(k_out)
+        else:
+            k_out, v_out = out
+        last = max(layer_indices)
+        slot = {l: i for i, l in enumerate(layer_indices)}
+        chunk = self.frame_chunk if self.frame_chunk > 0 else n
+        chunk = max(num_frames, chunk // num_frames * num_frames)  # whole clips keep (frame % T) aligned
+        for f0 in range(0, n, chunk):
+            nf = min(chunk, n - f0)
+            ws = self._workspace(nf, 1)
+            qkv = ws["qkv"][0]
+            M = nf * tok
+            self._embed(frames[f0:f0 + nf], ws, p)
+            for l in range(last + 1):
+                exp = None
+                if l in slot:
+                    i = slot[l]
+                    exp = (k_out[i, f0 * P:(f0 + nf) * P], v_out[i, f0 * P:(f0 + nf) * P], temporal_pos, num_frames)
+                self._block(ws, p["blocks"][l], qkv, M, nf, kv_only=(l == last), export=exp)
+        return k_out, v_out

@@ -1,0 +1,117 @@
+/*
+ * dfdclip.h — C ABI of libdfdclip_hip.so: hand-written gfx950 (MI355X) kernels for DFD-CLIP's
+ * hot path (per-clip CLIP-ViT K/V extraction + temporal cross-attention decoder).
+ *
+ * The reference is pure Python on PyTorch ATen ops and has no FFI of its own;
+ * each entry point below replaces the ATen op sequence of the cited reference lines
+ * (paths under the reference tree).  All pointers are DEVICE pointers unless noted.  Every
+ * function enqueues on `stream` (a hipStream_t passed as void*; NULL = default stream) and
+ * returns without synchronising: 0 on success, DFD_ERR_* (<0) on failure with a message
+ * available from dfd_last_error().  No entry point allocates device memory; workspaces are
+ * passed in.  Thread-safe for distinct streams (the error string is thread-local).
+ */
+#ifndef DFDCLIP_H
+#define DFDCLIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFD_ABI_VERSION 1
+
+enum { DFD_F32 = 0, DFD_BF16 = 1 };
+
+enum {
+  DFD_OK = 0,
+  DFD_ERR_INVALID_ARG = -1, /* null pointer, unsupported shape/dtype, misaligned leading dimension */
+  DFD_ERR_LAUNCH = -2,      /* hipLaunchKernel / hipGetLastError reported a failure */
+  DFD_ERR_NO_DEVICE = -3    /* no gfx950 device visible */
+};
+
+/* Epilogues of dfd_gemm (applied to acc = A · Wᵀ, fp32 accumulator). */
+enum {
+  DFD_EPI_BIAS = 0,        /* C = acc + bias                      — nn.Linear                              */
+  DFD_EPI_BIAS_QUICKGELU,  /* C = g(acc + bias), g(u)=u·σ(1.702u) — c_fc + QuickGELU  (clip/model.py:166-168, :208-212) */
+  DFD_EPI_BIAS_RESIDUAL,   /* C(f32) += acc + bias                — out_proj / c_proj + residual (clip/model.py:222-223) */
+  DFD_EPI_PATCH_EMBED,     /* conv1-as-GEMM: scatter to token rows, + positional embedding, CLS row
+                              (clip/model.py:277-291)                                              */
+  DFD_EPI_QKV_EXPORT       /* C = acc + bias AND export of the K / V column blocks, CLS row dropped,
+                              temporal positional embedding added (clip/model.py:186-199,
+                              models.py:505-509, :326-334)                                        */
+};
+
+typedef struct dfd_gemm_extra {
+  /* PATCH_EMBED: encoder positional_embedding [tokens, N] f32.
+     QKV_EXPORT : decoder temporal positional embedding viewed [frames_per_clip, N/3] f32, or NULL. */
+  const float* pos;
+  const float* cls;        /* PATCH_EMBED: class_embedding [N] f32 */
+  void* k_export;          /* QKV_EXPORT: [n_frames*(tokens-1), N/3] in c_dtype, or NULL (no export) */
+  void* v_export;
+  int32_t tokens;          /* tokens per frame incl. CLS (197 for ViT-B/16) */
+  int32_t frames_per_clip; /* T */
+} dfd_gemm_extra;
+
+const char* dfd_last_error(void);          /* host pointer, valid until the thread's next failing call */
+int dfd_abi_version(void);
+int dfd_device_check(void);                /* DFD_OK iff device 0.. current is gfx950 */
+
+/* LayerNorm over the last dim, fp32 statistics, eps inside the sqrt
+ * (clip/model.py:157-163, models.py:58-68).  x f32 [rows, cols] (row stride ldx);
+ * y in y_dtype (row stride ldy); y may alias x when y_dtype == DFD_F32.
+ * cols % 4 == 0, cols <= 4096. */
+int dfd_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+                  int y_dtype, int64_t rows, int cols, float eps, void* stream);
+
+/* Frames [n_frames, 3, res, res] (f32) -> patch rows [n_frames*P, kpad] in out_dtype, column
+ * k = c*patch*patch + i*patch + j (the flatten order of conv1.weight [D,3,patch,patch]), columns
+ * >= 3*patch*patch zero-filled.  The patch conv (clip/model.py:264, :277) then is a plain GEMM. */
+int dfd_patchify(const float* frames, void* patches, int out_dtype, int n_frames, int res, int patch, int kpad,
+                 void* stream);
+
+/* C = epilogue(A[M,K] · W[N,K]ᵀ): A and W row-major in ab_dtype with leading dimensions lda / ldw
+ * (elements), fp32 accumulation on the matrix cores (bf16: v_mfma_f32_32x32x16_bf16 /
+ * 16x16x32; f32: v_mfma_f32_32x32x2_f32, exact fp32).  K % 32 == 0; 16-byte aligned rows.
+ * C row-major [*, ldc] in c_dtype (see the epilogue list for what "row" means). */
+int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int ab_dtype, void* C, int64_t ldc,
+             int c_dtype, const float* bias, int epilogue, const dfd_gemm_extra* extra, int64_t M, int N, int K,
+             void* stream);
+
+/* Encoder self-attention over the packed projection qkv [n_frames*tokens, 3*heads*head_dim]
+ * (column blocks q | k | v; head h = columns h*head_dim ..): out = softmax(q kᵀ · scale) v,
+ * out [n_frames*tokens, heads*head_dim] (clip/model.py:188-195).  head_dim == 64. */
+int dfd_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, int dtype, int n_frames,
+                      int tokens, int heads, int head_dim, float scale, void* stream);
+
+/* y[B,N] = epilogue(x[B,K] · W[N,K]ᵀ + bias), all f32 — the decoder's one-token-per-clip linears
+ * (models.py:130-131, :160-165).  epilogue: DFD_EPI_BIAS, _BIAS_QUICKGELU or _BIAS_RESIDUAL
+ * (y += ...).  B <= 64, K % 4 == 0. */
+int dfd_linear_rows(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t ldy,
+                    int epilogue, int B, int N, int K, void* stream);
+
+/* Decoder cross-attention of ONE query per clip over S = T*P exported keys/values, two branches
+ * averaged (models.py:136-146): softmax(q_s·k/√d) and tanh(q_c·k/√d)·2σ(−‖q_c−k‖₁/√d); keys of padded
+ * frames (frame_mask[b,t] == 0) get weight 0 in both (models.py:104, :124).
+ *   q          f32 [B, heads, 2*d]  (in_proj output: per head softmax query then CoDA query)
+ *   k, v       kv_dtype [B, S, heads*d]
+ *   frame_mask u8 [B, T], S == T * patches
+ *   mix        f32 [B, heads*d]
+ *   stats      f32 [B, heads, 2] = (row max, sum of exp) of the softmax branch, kept for backward
+ *   workspace  f32, at least dfd_decoder_attn_workspace(B, heads, d, splits) bytes. */
+size_t dfd_decoder_attn_workspace(int B, int heads, int d, int splits);
+int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v, int kv_dtype, const uint8_t* frame_mask,
+                         float* mix, float* stats, void* workspace, int splits, int B, int T, int patches,
+                         int heads, int d, void* stream);
+
+/* Head: video_feature = LayerNorm(x) (ln_post), z = video_feature @ proj [D, out_dim],
+ * logits = 5 z / (‖z‖₂ + 1e-10)  (models.py:342-343, :359, :551-553).  All f32. */
+int dfd_head_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* proj,
+                 float* video_feature, float* raw_logits, float* logits, int B, int D, int out_dim, float eps,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFDCLIP_H */

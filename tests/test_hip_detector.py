@@ -1,0 +1,110 @@
+"""GPU parity of the whole hot path through the drop-in `Detector`, against the golden
+vectors produced by the reference itself (tests/golden) and against the CPU oracle on the same
+seeded inputs.  Bars (BASELINE.json north_star): fp32 path — logits within 1e-3 of the
+reference's fp32 CPU result; bf16 path — reported tolerance 3e-2 on logits of L2 norm 5
+(the reference's own CPU bf16-autocast run differs from its fp32 run by 4e-3)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+from tests.cases import build_case, load_golden, oracle_kwargs
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-3
+BF16_TOL = 3e-2
+SUPPORTED = ["tiny", "tiny_stride", "tiny_nopos", "tiny_augq", "small"]
+
+
+def make_detector(case, precision):
+    from dfd_clip_amd.detector import Detector
+    det = Detector(case["cfg"], case["T"], None, precision=precision)
+    det.load_state_dict(case["sd"])
+    return det.to("cuda").eval()
+
+
+@pytest.mark.parametrize("name", SUPPORTED)
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_detector_logits_match_reference(name, precision):
+    case = build_case(name)
+    g = load_golden(name)
+    det = make_detector(case, precision)
+    x, m, y = case["x"].cuda(), case["m"].cuda(), case["y"].cuda()
+    losses, logits = det(x, [y], m, single_task=0)
+    plog, feats = det.predict(x, m, with_video_features=True)
+    tol = FP32_TOL if precision == "fp32" else BF16_TOL
+    err = np.abs(logits[0].cpu().numpy() - g["logits"]).max()
+    print(f"{name}/{precision}: max |dlogit| = {err:.3e}")
+    assert err <= tol
+    assert torch.equal(plog[0], logits[0])
+    np.testing.assert_allclose(feats["video"].cpu().numpy(), g["video_feature"], atol=tol * 2, rtol=0)
+    np.testing.assert_allclose(losses[0].cpu().numpy(), g["losses"], atol=tol * 2, rtol=0)
+    np.testing.assert_allclose(logits[0].norm(dim=-1).cpu().numpy(), 5.0, atol=1e-4)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_encoder_reference_api_per_layer(precision):
+    """`encoder(x, with_out, with_q)` returns the reference's per-block dicts (clip/model.py:276-294)."""
+    case = build_case("tiny")
+    g = load_golden("tiny")
+    det = make_detector(case, precision)
+    kvs = det.encoder(case["x"].flatten(0, 1).cuda(), with_out=True, with_q=True)
+    assert len(kvs) == case["layers"]
+    tol = 2e-4 if precision == "fp32" else 6e-2
+    for l, d in enumerate(kvs):
+        assert set(d) == {"q", "k", "v", "out"}
+        for key in ("q", "k", "v", "out"):
+            assert tuple(d[key].shape) == g[f"enc{l}_{key}"].shape
+            np.testing.assert_allclose(d[key].float().cpu().numpy(), g[f"enc{l}_{key}"], atol=tol, rtol=0, err_msg=f"{l}/{key}")
+
+
+def test_exported_kv_layout_matches_oracle():
+    """extract_kv = encoder k/v with CLS dropped, (clip, frame, patch) row order, pos added."""
+    case = build_case("small")
+    det = make_detector(case, "fp32")
+    B, T = case["B"], case["T"]
+    k, v = det.encoder.extract_kv(case["x"].flatten(0, 1).cuda(), case["layer_indices"], T, det.decoder.temporal_pos())
+    kvs = ref_cpu.encoder_forward(case["sd"], case["x"].flatten(0, 1), case["heads"], case["patch"])
+    pos = case["sd"]["decoder.positional_embedding"]
+    for i, l in enumerate(case["layer_indices"]):
+        for name, got in (("k", k), ("v", v)):
+            want = kvs[l][name][:, 1:].unflatten(0, (B, T)) + pos
+            np.testing.assert_allclose(got[i].cpu().numpy().reshape(want.shape), want.numpy(), atol=2e-4, rtol=0)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_vitb16_cfg1_matches_reference(precision):
+    """BASELINE.json configs[0]: ViT-B/16, 2 clips x 8 frames, decode_indices 6..11."""
+    case = build_case("vitb16_cfg1")
+    g = load_golden("vitb16_cfg1")
+    det = make_detector(case, precision)
+    x, m, y = case["x"].cuda(), case["m"].cuda(), case["y"].cuda()
+    losses, logits = det(x, [y], m, single_task=0)
+    err = np.abs(logits[0].cpu().numpy() - g["logits"]).max()
+    print(f"vitb16_cfg1/{precision}: max |dlogit| = {err:.3e}")
+    assert err <= (FP32_TOL if precision == "fp32" else BF16_TOL)
+    rows = list(g["slice_rows"])
+    enc = det.encoder(case["x"].flatten(0, 1)[[0, 15]].cuda())
+    tol = 5e-4 if precision == "fp32" else 1e-1
+    for l in (6, 11):
+        for key in ("k", "v"):
+            for i, fr in enumerate((0, 15)):
+                np.testing.assert_allclose(enc[l][key][i, rows].float().cpu().numpy(), g[f"enc{l}_{key}_f{fr}"], atol=tol, rtol=0)
+
+
+def test_frame_chunking_is_bit_identical():
+    case = build_case("small")
+    det = make_detector(case, "bf16")
+    x = case["x"].flatten(0, 1).cuda()
+    a = det.encoder.extract_kv(x, case["layer_indices"], case["T"], det.decoder.temporal_pos())
+    det.encoder.frame_chunk = case["T"]
+    b = det.encoder.extract_kv(x, case["layer_indices"], case["T"], det.decoder.temporal_pos())
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_num_frames_mismatch_raises():
+    case = build_case("tiny")
+    det = make_detector(case, "fp32")
+    with pytest.raises(RuntimeError):
+        det.predict(case["x"][:, :3].cuda(), case["m"][:, :3].cuda())

@@ -1,0 +1,202 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (ctypes) against the CPU oracle /
+plain fp32 math on the same seeded inputs.  Tolerances: f32 kernels 2e-4 absolute on O(1..10)
+values (different summation order only); bf16 kernels are checked against fp32 math on the
+SAME bf16-rounded operands, so what is left is fp32-accumulation order plus one final
+rounding to bf16 (half an ulp = 2^-9 relative)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from dfd_clip_amd import capi as c
+    c.load_library()
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    assert c.load_library().dfd_device_check() == 0, c.load_library().dfd_last_error()
+    return c
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.from_numpy(np.random.default_rng(seed).standard_normal(shape).astype(np.float32) * scale)
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def assert_close(got, want, atol, rtol=0.0, msg=""):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    err = (got - want).abs()
+    lim = atol + rtol * want.abs()
+    assert torch.isfinite(got).all(), f"{msg}: non-finite output"
+    assert (err <= lim).all(), f"{msg}: max err {err.max().item():.3e} (limit {lim.min().item():.3e}) at {err.argmax().item()}"
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 128), (7, 768), (1000, 768), (33, 1024), (5, 256)])
+def test_layernorm(capi, rows, cols):
+    x = rnd(rows, cols, seed=1, scale=3.0) + 0.5
+    g, b = 1 + 0.1 * rnd(cols, seed=2), 0.1 * rnd(cols, seed=3)
+    want = F.layer_norm(x, (cols,), g, b, 1e-5)
+    xd, gd, bd = x.cuda(), g.cuda(), b.cuda()
+    out = torch.empty_like(xd)
+    capi.layernorm(xd, gd, bd, out)
+    assert_close(out, want, 2e-5, msg="f32")
+    outb = torch.empty(rows, cols, device="cuda", dtype=torch.bfloat16)
+    capi.layernorm(xd, gd, bd, outb)
+    assert_close(outb, want, 1e-5, rtol=2 ** -8, msg="bf16")
+    capi.layernorm(xd, gd, bd, xd)  # in place
+    assert_close(xd, want, 2e-5, msg="in place")
+
+
+@pytest.mark.parametrize("res,patch,width", [(32, 16, 128), (224, 16, 256), (224, 14, 128)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_patch_embed_is_conv1_plus_cls_plus_pos(capi, res, patch, width, dtype):
+    n = 3
+    P = (res // patch) ** 2
+    tokens = P + 1
+    frames = rnd(n, 3, res, res, seed=4)
+    w = rnd(width, 3, patch, patch, seed=5, scale=(3 * patch * patch) ** -0.5)
+    cls, pos = rnd(width, seed=6), rnd(tokens, width, seed=7)
+    fr, wr = (frames, w) if dtype == torch.float32 else (bf16_round(frames), bf16_round(w))
+    y = F.conv2d(fr, wr, None, stride=patch).reshape(n, width, -1).permute(0, 2, 1)
+    want = torch.cat([cls.view(1, 1, -1).expand(n, 1, width), y], dim=1) + pos
+    kreal = 3 * patch * patch
+    kpad = (kreal + 31) // 32 * 32
+    patches = torch.zeros(n * P, kpad, device="cuda", dtype=dtype)
+    capi.patchify(frames.cuda(), patches, res, patch)
+    wp = torch.zeros(width, kpad)
+    wp[:, :kreal] = w.reshape(width, kreal)
+    x = torch.zeros(n * tokens, width, device="cuda")
+    capi.gemm(patches, wp.to(dtype).cuda(), x, None, capi.EPI_PATCH_EMBED, pos=pos.cuda(), cls=cls.cuda(), tokens=tokens)
+    assert_close(x.view(n, tokens, width), want, 2e-4 if dtype == torch.float32 else 2e-3, msg="patch embed")
+
+
+@pytest.mark.parametrize("M,N,K", [(5, 8, 32), (300, 200, 64), (591, 384, 128), (1000, 2304, 768), (257, 768, 3072)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(capi, M, N, K, dtype):
+    a, w, bias = rnd(M, K, seed=8), rnd(N, K, seed=9, scale=K ** -0.5), rnd(N, seed=10, scale=0.1)
+    ar, wr = (a, w) if dtype == torch.float32 else (bf16_round(a), bf16_round(w))
+    ref = ar.double() @ wr.double().T + bias.double()
+    atol = 1e-4 if dtype == torch.float32 else 1e-4
+    rtol = 1e-5 if dtype == torch.float32 else 2 ** -8
+    ad, wd, bd = a.to(dtype).cuda(), w.to(dtype).cuda(), bias.cuda()
+    c = torch.empty(M, N, device="cuda", dtype=dtype)
+    capi.gemm(ad, wd, c, bd, capi.EPI_BIAS)
+    assert_close(c, ref, atol, rtol, "bias")
+    capi.gemm(ad, wd, c, bd, capi.EPI_BIAS_QUICKGELU)
+    assert_close(c, ref * torch.sigmoid(1.702 * ref), atol, rtol, "quickgelu")
+    x0 = rnd(M, N, seed=11)
+    x = x0.clone().cuda()
+    capi.gemm(ad, wd, x, bd, capi.EPI_BIAS_RESIDUAL)
+    assert_close(x, x0.double() + ref, 2e-4, 1e-5, "residual")
+    if dtype == torch.bfloat16:  # bf16 operands, f32 output
+        cf = torch.empty(M, N, device="cuda")
+        capi.gemm(ad, wd, cf, bd, capi.EPI_BIAS)
+        assert_close(cf, ref, 1e-4, 1e-5, "bf16->f32")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_qkv_export_layout(capi, dtype):
+    """K/V column blocks land in [frames*P, D] with the CLS row dropped and pos[frame % T] added."""
+    n, tokens, D, T = 6, 5, 128, 3
+    M = n * tokens
+    a, w, bias = rnd(M, D, seed=12), rnd(3 * D, D, seed=13, scale=D ** -0.5), rnd(3 * D, seed=14, scale=0.1)
+    tpos = rnd(T, D, seed=15)
+    ar, wr = (a, w) if dtype == torch.float32 else (bf16_round(a), bf16_round(w))
+    ref = (ar.double() @ wr.double().T + bias.double()).float().view(n, tokens, 3, D)
+    c = torch.empty(M, 3 * D, device="cuda", dtype=dtype)
+    ke = torch.zeros(n * (tokens - 1), D, device="cuda", dtype=dtype)
+    ve = torch.zeros_like(ke)
+    capi.gemm(a.to(dtype).cuda(), w.to(dtype).cuda(), c, bias.cuda(), capi.EPI_QKV_EXPORT, pos=tpos.cuda(), k_export=ke,
+              v_export=ve, tokens=tokens, frames_per_clip=T)
+    tol = dict(atol=1e-4, rtol=1e-5) if dtype == torch.float32 else dict(atol=1e-4, rtol=2 ** -8)
+    assert_close(c.view(n, tokens, 3, D), ref, msg="qkv", **tol)
+    pos_f = tpos[torch.arange(n) % T].view(n, 1, D)
+    assert_close(ke.view(n, tokens - 1, D), ref[:, 1:, 1] + pos_f, msg="k export", **tol)
+    assert_close(ve.view(n, tokens - 1, D), ref[:, 1:, 2] + pos_f, msg="v export", **tol)
+    c2 = torch.empty_like(c)
+    capi.gemm(a.to(dtype).cuda(), w.to(dtype).cuda(), c2, bias.cuda(), capi.EPI_QKV_EXPORT, tokens=tokens)  # no export
+    assert torch.equal(c, c2)
+
+
+@pytest.mark.parametrize("n,tokens,heads", [(2, 5, 2), (3, 197, 4), (1, 257, 2), (2, 50, 12)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_encoder_attention(capi, n, tokens, heads, dtype):
+    D = heads * 64
+    qkv = rnd(n * tokens, 3 * D, seed=16)
+    qkv[:, :D] *= 2.0  # peaky softmax rows
+    q = qkv if dtype == torch.float32 else bf16_round(qkv)
+    t = q.view(n, tokens, 3, heads, 64)
+    aff = torch.einsum("nqhc,nkhc->nqkh", t[:, :, 0] / 8.0, t[:, :, 1]).softmax(dim=-2)
+    want = torch.einsum("nqlh,nlhc->nqhc", aff, t[:, :, 2]).reshape(n * tokens, D)
+    out = torch.empty(n * tokens, D, device="cuda", dtype=dtype)
+    capi.attention_fwd(qkv.to(dtype).cuda(), out, n, tokens, heads)
+    if dtype == torch.float32:
+        assert_close(out, want, 2e-5, 1e-5, "attention f32")
+    else:  # P is rounded to bf16 before the PV product in the MFMA kernel
+        assert_close(out, want, 2e-2, 2 ** -7, "attention bf16")
+
+
+@pytest.mark.parametrize("B,T,P,heads", [(2, 4, 4, 2), (3, 3, 196, 4), (2, 8, 196, 12), (1, 5, 256, 16)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decoder_attention(capi, B, T, P, heads, dtype):
+    D, S = heads * 64, T * P
+    k, v = rnd(B, S, heads, 64, seed=17), rnd(B, S, heads, 64, seed=18)
+    q = rnd(B, 1, heads, 128, seed=19)
+    m = torch.ones(B, T, dtype=torch.bool)
+    if B > 1:
+        m[1, T - max(1, T // 4):] = False
+    kr, vr = (k, v) if dtype == torch.float32 else (bf16_round(k), bf16_round(v))
+    # oracle attention with identity projections: feed q through in_proj = I
+    w = {"p.attn.in_proj.weight": torch.eye(2 * D), "p.attn.in_proj.bias": torch.zeros(2 * D),
+         "p.attn.out_proj.weight": torch.eye(D), "p.attn.out_proj.bias": torch.zeros(D)}
+    want = ref_cpu.decoder_attention(q.reshape(B, 1, 2 * D), kr, vr, m.repeat_interleave(P, dim=-1), w, "p.", heads, T)
+    splits = 3
+    ws = torch.empty(capi.decoder_attn_workspace_bytes(B, heads, 64, splits) // 4, device="cuda")
+    mix = torch.empty(B, D, device="cuda")
+    stats = torch.empty(B, heads, 2, device="cuda")
+    capi.decoder_attn_fwd(q.reshape(B, 2 * D).cuda(), k.to(dtype).reshape(B, S, D).cuda(), v.to(dtype).reshape(B, S, D).cuda(),
+                          m.to(torch.uint8).cuda(), mix, stats, ws, splits, B, T, P, heads)
+    assert_close(mix, want.reshape(B, D), 2e-5, 1e-4, "decoder attention")
+    # (max, sumexp) of the softmax branch
+    s = torch.einsum("bhc,bshc->bsh", q[:, 0, :, :64] / 8.0, kr).masked_fill(~m.repeat_interleave(P, dim=-1).unsqueeze(-1), -math.inf)
+    assert_close(stats[..., 0], s.max(dim=1).values, 1e-5, 1e-5, "row max")
+    assert_close(stats[..., 1], (s - s.max(dim=1, keepdim=True).values).exp().sum(dim=1), 1e-4, 1e-4, "sumexp")
+
+
+@pytest.mark.parametrize("B,N,K", [(1, 8, 128), (2, 256, 128), (16, 1536, 768), (16, 768, 3072), (9, 100, 64)])
+def test_linear_rows(capi, B, N, K):
+    x, w, b = rnd(B, K, seed=20), rnd(N, K, seed=21, scale=K ** -0.5), rnd(N, seed=22, scale=0.1)
+    ref = x.double() @ w.double().T + b.double()
+    y = torch.empty(B, N, device="cuda")
+    capi.linear_rows(x.cuda(), w.cuda(), b.cuda(), y)
+    assert_close(y, ref, 2e-5, 1e-5, "bias")
+    capi.linear_rows(x.cuda(), w.cuda(), b.cuda(), y, capi.EPI_BIAS_QUICKGELU)
+    assert_close(y, ref * torch.sigmoid(1.702 * ref), 2e-5, 1e-5, "quickgelu")
+    y0 = rnd(B, N, seed=23)
+    y = y0.clone().cuda()
+    capi.linear_rows(x.cuda(), w.cuda(), b.cuda(), y, capi.EPI_BIAS_RESIDUAL)
+    assert_close(y, y0.double() + ref, 2e-5, 1e-5, "residual")
+
+
+@pytest.mark.parametrize("B,D,od", [(2, 128, 2), (16, 768, 2), (3, 1024, 140)])
+def test_head(capi, B, D, od):
+    x, g, b, proj = rnd(B, D, seed=24, scale=2.0), 1 + 0.1 * rnd(D, seed=25), 0.1 * rnd(D, seed=26), rnd(D, od, seed=27, scale=D ** -0.5)
+    feat_ref = F.layer_norm(x, (D,), g, b, 1e-5)
+    z = feat_ref @ proj
+    feat = torch.empty(B, D, device="cuda")
+    raw = torch.empty(B, od, device="cuda")
+    logits = torch.empty(B, od, device="cuda")
+    capi.head_fwd(x.cuda(), g.cuda(), b.cuda(), proj.cuda(), feat, raw, logits)
+    assert_close(feat, feat_ref, 2e-5, msg="feature")
+    assert_close(raw, z, 2e-5, 1e-5, "raw logits")
+    assert_close(logits, ref_cpu.normalise_logits(z), 5e-5, 1e-5, "logits")
+    assert_close(logits.norm(dim=-1), torch.full((B,), 5.0), 1e-4, msg="norm 5")

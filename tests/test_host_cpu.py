@@ -1,0 +1,84 @@
+"""CPU checks of host-side logic: config node, weight schema / seed recipe, Detector
+construction and state_dict schema, layer-index resolution."""
+import numpy as np
+import pytest
+import torch
+
+from dfd_clip_amd.build import build
+from dfd_clip_amd.config import ConfigNode, default_detector_config
+from dfd_clip_amd.weights import ARCHS, decoder_schema, encoder_schema, random_state_dict, resolve_layer_indices, synthetic_clips
+from tests.cases import build_case, make_config
+
+
+def test_config_node_behaviours():
+    c = default_detector_config()
+    assert c.decode_mode == "stride" and c.decode_stride == 2 and c.adapter.type == "none"
+    assert "temporal_position" in c.op_mode and "attn_mode" not in c.op_mode
+    c.op_mode.attn_mode = "frame"
+    assert c["op_mode"]["attn_mode"] == "frame"
+    c2 = c.clone()
+    c2.op_mode.attn_mode = "x"
+    assert c.op_mode.attn_mode == "frame"
+    with pytest.raises(AttributeError):
+        c.nope
+    assert isinstance(ConfigNode({"a": {"b": 1}}).a, ConfigNode)
+
+
+def test_layer_indices():
+    c = default_detector_config()
+    assert resolve_layer_indices(c, 12) == [0, 2, 4, 6, 8, 10]
+    c.decode_mode, c.decode_indices = "index", [6, 7, 8, 9, 10, 11]
+    assert resolve_layer_indices(c, 12) == [6, 7, 8, 9, 10, 11]
+
+
+def test_schema_sizes_match_survey():
+    enc = encoder_schema("ViT-B/16")
+    assert sum(int(np.prod(s)) for s in enc.values()) == 86_192_640
+    dec = decoder_schema("ViT-B/16", 8, 6, [2])
+    assert sum(int(np.prod(s)) for s in dec.values()) == 38_995_200
+
+
+def test_seed_recipe_is_deterministic():
+    cfg = make_config("tiny", decode_mode="index", decode_indices=[0, 1])
+    a, b = random_state_dict(cfg, 4, seed=0), random_state_dict(cfg, 4, seed=0)
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    c = random_state_dict(cfg, 4, seed=1)
+    assert not torch.equal(a["encoder.proj"], c["encoder.proj"])
+    x, m, y = synthetic_clips(2, 8, 32)
+    assert x.shape == (2, 8, 3, 32, 32) and m[0].all() and m[1].tolist() == [True] * 6 + [False] * 2 and y.tolist() == [0, 1]
+
+
+def test_detector_state_dict_schema_and_roundtrip():
+    build()
+    from dfd_clip_amd.detector import Detector
+    case = build_case("tiny_augq")
+    det = Detector(case["cfg"], case["T"], None, precision="fp32")
+    assert list(det.state_dict().keys()) != []
+    assert set(det.state_dict().keys()) == set(case["sd"].keys())
+    for k, v in det.state_dict().items():
+        assert tuple(v.shape) == tuple(case["sd"][k].shape), k
+    det.load_state_dict(case["sd"])
+    assert all(not p.requires_grad for p in det.encoder.parameters())
+    trainable = [n for n, p in det.named_parameters() if p.requires_grad]
+    assert trainable and all(n.startswith("decoder.") for n in trainable)
+    opt = det.configure_optimizers(0.01)
+    assert opt.defaults["momentum"] == 0.95 and opt.defaults["weight_decay"] == 0.01
+    assert det.out_dim == [2] and det.layer_indices == [0, 1] and callable(det.transform)
+    with pytest.raises(Exception):
+        det.predict(case["x"], case["m"])  # CPU tensors: no fallback path
+
+
+def test_full_size_schema_matches_reference_key_count():
+    from dfd_clip_amd.detector import Detector
+    cfg = make_config("ViT-B/16", decode_mode="index", decode_indices=[6, 7, 8, 9, 10, 11])
+    det = Detector(cfg, 8, None)
+    keys = det.state_dict().keys()
+    assert len(keys) == 152 + 79  # encoder 152 + decoder 79
+    assert sum(p.numel() for p in det.parameters() if p.requires_grad) == 38_995_200
+
+
+def test_unbuilt_variants_raise():
+    from dfd_clip_amd.detector import Detector
+    cfg = make_config("tiny", adapter__type="normal", adapter__struct={"type": "768-x-768-nln", "x": 32})
+    with pytest.raises(NotImplementedError):
+        Detector(cfg, 4, None)
