@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 1-second clips per second through the DFD-CLIP hot path on MI355X.
+
+One step = one pass of the hot path over one batch of synthetic clips that is already
+resident in HBM: `Detector.predict` on x [16, 30, 3, 224, 224] (BASELINE.json configs[1]:
+ViT-B/16, 16 clips x 30 frames, bf16, forward-only inference.py path), per GPU.  With
+--gpus N the driver launches one rank per GPU (torch.distributed, backend nccl = RCCL); clips
+are independent, so ranks shard them with no data-path collective except the evaluation
+contract's all-gather of per-clip logits; scaling is weak (16 clips per GPU).
+
+Prints ONE JSON line on rank 0 with the whole-job clips/s plus
+  roofline     — the dominant kernel (the MLP c_fc GEMM, M x 3072 x 768 with QuickGELU epilogue):
+                 algorithmic FLOPs per launch / its average launch duration measured with HIP
+                 events on the launch stream during the timed steps, against the 2.5 PFLOP/s
+                 dense bf16 MFMA peak;
+  cpu_baseline — the CPU oracle (this repo's PyTorch-CPU port of the reference path) timed on
+                 this host on a bounded sample (one 30-frame clip), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--arch", default="ViT-B/16")
+    ap.add_argument("--clips", type=int, default=16, help="clips per GPU per step")
+    ap.add_argument("--frames", type=int, default=30)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--frame-chunk", type=int, default=-1, help="frames per encoder pass (-1 = package default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(args, device):
+    from dfd_clip_amd.detector import Detector
+    from dfd_clip_amd.weights import ARCHS, random_state_dict
+    cfg = Detector.get_default_config()
+    cfg.architecture = args.arch
+    cfg.out_dim = [2]
+    cfg.losses = ["auc_roc"]
+    layers = ARCHS[args.arch][3]
+    if args.arch == "ViT-B/16":
+        cfg.decode_mode, cfg.decode_indices = "index", [6, 7, 8, 9, 10, 11]  # every configs/deepfake/*.yaml
+    else:
+        cfg.decode_mode, cfg.decode_stride = "stride", 2
+    sd = random_state_dict(cfg, args.frames, seed=0)
+    det = Detector(cfg, args.frames, None, precision=args.precision)
+    det.load_state_dict(sd)
+    det = det.to(device).eval()
+    if args.frame_chunk >= 0:
+        det.encoder.frame_chunk = args.frame_chunk
+    return det, cfg, sd, layers
+
+
+def cpu_baseline(cfg, sd, args):
+    """The oracle as the CPU baseline ("port"): one T-frame clip, fp32, no_grad, all host threads."""
+    from oracle import ref_cpu
+    from dfd_clip_amd.weights import ARCHS, resolve_layer_indices, synthetic_clips
+    res, patch, width, layers, heads, _ = ARCHS[args.arch]
+    x, m, _ = synthetic_clips(1, args.frames, res, seed=1234, masked_tail=False)
+    kw = dict(heads=heads, patch=patch, layer_indices=resolve_layer_indices(cfg, layers), out_dims=[2],
+              num_frames=args.frames)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = min(cores, 16)  # the GPU box gives one GPU's job a 16-core share; more threads only oversubscribe
+    torch.set_num_threads(cores)
+    times = []
+    with torch.no_grad():
+        for i in range(3):
+            t0 = time.perf_counter()
+            ref_cpu.detector_predict(sd, x, m, **kw)
+            times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[0] if len(times) > 1 else times[0]
+    return {"value": round(1.0 / t, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"1 clip x {args.frames} frames {args.arch} fp32, oracle/ref_cpu.detector_predict, best of 2 after 1 warm-up, "
+                      f"torch {torch.__version__} CPU threads={cores}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from dfd_clip_amd import capi
+    from dfd_clip_amd.weights import ARCHS
+    det, cfg, sd, layers = build_model(args, device)
+    res, patch, width, _, heads, _ = ARCHS[args.arch]
+    B, T = args.clips, args.frames
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    x = torch.randn(B, T, 3, res, res, device=device, generator=g)
+    m = torch.ones(B, T, dtype=torch.bool, device=device)
+    tokens = (res // patch) ** 2 + 1
+    M = B * T * tokens
+
+    def step():
+        logits, _ = det.predict(x, m)
+        if dist is not None:  # evaluation contract: gather per-clip logits (reference callbacks/metrics.py:98-99)
+            out = [torch.empty_like(logits[0]) for _ in range(world)]
+            dist.all_gather(out, logits[0])
+        return logits
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # dominant kernel: c_fc GEMM (M x 4D x D, QuickGELU epilogue); HIP events on the launch stream
+    capi.profile_gemm(epilogue=capi.EPI_BIAS_QUICKGELU)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    spans = capi.profile_gemm_collect()
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+
+    if rank == 0:
+        flops = 2.0 * M * (4 * width) * width
+        avg_ms = sum(spans) / max(1, len(spans))
+        achieved = flops / (avg_ms * 1e-3) / 1e12 if spans else None
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "1-sec clips/sec (30x224x224 frames) ViT-B/16", "value": round(world * B * args.steps / dt, 3),
+            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {args.arch} forward-only Detector.predict (inference.py path), "
+                                   f"{B} clips x {T} frames x 3x{res}x{res} per GPU, decode layers {det.layer_indices}, "
+                                   f"random-init weights, inputs resident in HBM",
+                       "clips_per_gpu": B, "frames_per_clip": T, "frame_chunk": det.encoder.frame_chunk},
+            "roofline": {"bound": "mfma", "kernel": "c_fc GEMM + QuickGELU (M=%d, N=%d, K=%d)" % (M, 4 * width, width),
+                         "achieved": round(achieved, 2) if achieved else None, "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,
+                         "launches_timed": len(spans), "avg_launch_ms": round(avg_ms, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, args)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

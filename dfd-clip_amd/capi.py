@@ -112,6 +112,23 @@ def patchify(frames, out, res, patch):
     return out
 
 
+_profile = {"epilogue": None, "events": []}
+
+
+def profile_gemm(epilogue=None):
+    """Time every `gemm` launch with this epilogue from now on: a HIP event pair is recorded on
+    the launch stream around the kernel (bench.py's roofline leg).  None switches it off."""
+    _profile["epilogue"] = epilogue
+    _profile["events"] = []
+
+
+def profile_gemm_collect():
+    """Milliseconds of each timed launch since `profile_gemm`; call after a device sync."""
+    spans = [a.elapsed_time(b) for a, b in _profile["events"]]
+    profile_gemm(None)
+    return spans
+
+
 def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_export=None, v_export=None, tokens=0,
          frames_per_clip=0):
     """c = epilogue(a[M,K] @ w[N,K]^T).  `m` limits the rows used (buffers may be over-allocated)."""
@@ -121,8 +138,15 @@ def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_ex
     N, K = w.shape
     assert a.shape[1] == K
     extra = GemmExtra(_ptr(pos).value, _ptr(cls).value, _ptr(k_export).value, _ptr(v_export).value, tokens, frames_per_clip)
+    timed = _profile["epilogue"] == epilogue
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _check(load_library().dfd_gemm(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _DTYPE[a.dtype], _ptr(c), c.stride(0),
                                    _DTYPE[c.dtype], _ptr(bias), epilogue, ctypes.byref(extra), M, N, K, _stream()), "dfd_gemm")
+    if timed:
+        e1.record()
+        _profile["events"].append((e0, e1))
     return c
 
 
