@@ -57,4 +57,5 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float quick_gelu(float u) { return u / (1.0f + __expf(-1.702f * u)); }
+// u * sigmoid(1.702 u); v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE division sequence
+__device__ __forceinline__ float quick_gelu(float u) { return u * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u)); }

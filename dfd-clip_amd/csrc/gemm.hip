@@ -11,20 +11,7 @@
 //
 // Both A and W are K-contiguous, so both MFMA operands are plain 16-byte row reads: lane
 // (r = lane&31, h = lane>>5) holds A[row r][k-slice h] and W[row r][k-slice h].
-#include "common.hpp"
-
-struct GemmArgs {
-  const void* A;
-  const void* W;
-  void* C;
-  const float* bias;
-  const float* pos;
-  const float* cls;
-  void* k_export;
-  void* v_export;
-  int64_t lda, ldw, ldc, M;
-  int N, K, tokens, frames_per_clip;
-};
+#include "gemm_args.hpp"
 
 namespace {
 
@@ -212,9 +199,6 @@ int launch_gemm128(const GemmArgs& a, int epi, hipStream_t st) {
 }
 
 }  // namespace
-
-// tuned bf16 kernel (gemm256.hip); returns 1 when the shape is not eligible
-int dfd_gemm256_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st);
 
 extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int ab_dtype, void* C, int64_t ldc,
                         int c_dtype, const float* bias, int epilogue, const dfd_gemm_extra* extra, int64_t M, int N,

@@ -1,0 +1,19 @@
+// Argument block shared by the GEMM kernels (gemm.hip: general shapes; gemm256.hip: tuned bf16).
+#pragma once
+#include "common.hpp"
+
+struct GemmArgs {
+  const void* A;
+  const void* W;
+  void* C;
+  const float* bias;
+  const float* pos;
+  const float* cls;
+  void* k_export;
+  void* v_export;
+  int64_t lda, ldw, ldc, M;
+  int N, K, tokens, frames_per_clip;
+};
+
+// tuned bf16 kernel (gemm256.hip): 0 = launched, <0 = error, 1 = shape not eligible
+int dfd_gemm256_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st);
