@@ -129,8 +129,8 @@ class Decoder(nn.Module):
         assert L == len(self.layer_indices) and S == T * P and k_all.shape[2] == D
         mask = m.to(device=dev, dtype=torch.uint8).contiguous()
         f32 = dict(device=dev, dtype=torch.float32)
-        R = 256 // (8 * H) + 1
-        splits = max(1, min(S // (R * 8), max(1, 2048 // max(B, 1))))
+        # enough workgroups to fill 256 CUs a few times over, few enough partial states to merge cheaply
+        splits = max(1, min(S // 64, max(1, 768 // max(B, 1))))
         ws = torch.empty(capi.decoder_attn_workspace_bytes(B, H, 64, splits) // 4, **f32)
         g = lambda t: t.detach().to(torch.float32).contiguous()
 
