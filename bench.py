@@ -118,6 +118,7 @@ def main():
     tokens = (res // patch) ** 2 + 1
     M = B * T * tokens
 
+    @torch.no_grad()
     def step():
         logits, _ = det.predict(x, m)
         if dist is not None:  # evaluation contract: gather per-clip logits (reference callbacks/metrics.py:98-99)

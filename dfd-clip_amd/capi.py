@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT = range(5)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -41,8 +41,18 @@ SIGNATURES = {
     "dfd_attention_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dfd_linear_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "dfd_decoder_attn_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "dfd_decoder_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+    "dfd_decoder_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dfd_decoder_attn_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dfd_decoder_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dfd_linear_rows_bwd_weight": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dfd_transpose_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dfd_layernorm_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_int, c_float, c_int, c_void_p]),
+    "dfd_quickgelu": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dfd_head_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                             c_void_p]),
     "dfd_head_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                              c_int, c_float, c_void_p]),
 }
@@ -173,12 +183,13 @@ def decoder_attn_workspace_bytes(B, heads, d, splits):
     return load_library().dfd_decoder_attn_workspace(B, heads, d, splits)
 
 
-def decoder_attn_fwd(q, k, v, frame_mask, mix, stats, workspace, splits, B, T, patches, heads, d=64):
-    _dev(q, k, v, frame_mask, mix, stats, workspace)
+def decoder_attn_fwd(q, k, v, frame_mask, mix, stats, workspace, splits, B, T, patches, heads, d=64, mix_softmax=None):
+    _dev(q, k, v, frame_mask, mix, stats, workspace, mix_softmax)
     assert q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
     assert frame_mask.dtype == torch.uint8 and frame_mask.is_contiguous()
     _check(load_library().dfd_decoder_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _DTYPE[k.dtype], _ptr(frame_mask), _ptr(mix),
-                                               _ptr(stats), _ptr(workspace), splits, B, T, patches, heads, d, _stream()),
+                                               _ptr(mix_softmax), _ptr(stats), _ptr(workspace), splits, B, T, patches, heads, d,
+                                               _stream()),
            "dfd_decoder_attn_fwd")
     return mix
 
@@ -190,3 +201,64 @@ def head_fwd(x, gamma, beta, proj, feat, raw, logits, eps=1e-5):
     _check(load_library().dfd_head_fwd(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(proj), _ptr(feat), _ptr(raw),
                                        _ptr(logits), B, D, proj.shape[1], eps, _stream()), "dfd_head_fwd")
     return logits
+
+
+# ---- decoder backward ------------------------------------------------------------------------
+
+def decoder_attn_bwd_workspace_bytes(B, T, heads, d=64):
+    return load_library().dfd_decoder_attn_bwd_workspace(B, T, heads, d)
+
+
+def decoder_attn_bwd(q, k, v, frame_mask, dmix, mix_softmax, stats, dq, dpos, workspace, B, T, patches, heads, d=64, dk=None,
+                     dv=None):
+    _dev(q, k, v, frame_mask, dmix, mix_softmax, stats, dq, dpos, workspace, dk, dv)
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and dmix.is_contiguous() and mix_softmax.is_contiguous()
+    _check(load_library().dfd_decoder_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _DTYPE[k.dtype], _ptr(frame_mask), _ptr(dmix),
+                                               _ptr(mix_softmax), _ptr(stats), _ptr(dq), _ptr(dpos), _ptr(dk), _ptr(dv),
+                                               _ptr(workspace), B, T, patches, heads, d, _stream()), "dfd_decoder_attn_bwd")
+    return dq
+
+
+def linear_rows_bwd_weight(dy, x, dw, db=None):
+    _dev(dy, x, dw, db)
+    assert dy.stride(1) == 1 and x.stride(1) == 1 and dw.is_contiguous()
+    B, N = dy.shape
+    K = x.shape[1]
+    assert tuple(dw.shape) == (N, K)
+    _check(load_library().dfd_linear_rows_bwd_weight(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), _ptr(db), B, N, K,
+                                                     _stream()), "dfd_linear_rows_bwd_weight")
+    return dw
+
+
+def transpose(src, dst):
+    _dev(src, dst)
+    assert src.is_contiguous() and dst.is_contiguous() and src.dtype == torch.float32
+    R, C = src.shape
+    _check(load_library().dfd_transpose_f32(_ptr(src), _ptr(dst), R, C, _stream()), "dfd_transpose_f32")
+    return dst
+
+
+def layernorm_bwd(x, gamma, dy, dx, dgamma, dbeta, xhat_ws, accumulate_dx=False, eps=1e-5):
+    _dev(x, gamma, dy, dx, dgamma, dbeta, xhat_ws)
+    rows, cols = x.shape
+    _check(load_library().dfd_layernorm_bwd(_ptr(x), x.stride(0), _ptr(gamma), _ptr(dy), dy.stride(0), _ptr(dx), dx.stride(0),
+                                            _ptr(dgamma), _ptr(dbeta), _ptr(xhat_ws), rows, cols, eps, int(accumulate_dx),
+                                            _stream()), "dfd_layernorm_bwd")
+    return dx
+
+
+def quickgelu(u, out, du=None):
+    _dev(u, out, du)
+    assert u.is_contiguous() and out.is_contiguous() and (du is None or du.is_contiguous())
+    _check(load_library().dfd_quickgelu(_ptr(u), _ptr(du), _ptr(out), u.numel(), _stream()), "dfd_quickgelu")
+    return out
+
+
+def head_bwd(raw, dlogits, proj, feat, dfeat_ext, dz, dfeat, dproj):
+    _dev(raw, dlogits, proj, feat, dfeat_ext, dz, dfeat, dproj)
+    B, od = raw.shape
+    D = proj.shape[0]
+    assert dlogits.is_contiguous() and proj.is_contiguous() and feat.is_contiguous()
+    _check(load_library().dfd_head_bwd(_ptr(raw), _ptr(dlogits), _ptr(proj), _ptr(feat), _ptr(dfeat_ext), _ptr(dz), _ptr(dfeat),
+                                       _ptr(dproj), B, D, od, _stream()), "dfd_head_bwd")
+    return dfeat

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(1024) void decoder_attn_partial_kernel(const float*
 }
 
 __global__ void decoder_attn_combine_kernel(const float* __restrict__ ws, float* __restrict__ mix,
-                                            float* __restrict__ stats, int splits, int heads) {
+                                            float* __restrict__ mix_softmax, float* __restrict__ stats, int splits,
+                                            int heads) {
   const int b = blockIdx.x;
   const int hd = threadIdx.x / HD, c = threadIdx.x % HD;
   const float* base = ws + ((int64_t)b * splits * heads + hd) * PART;
@@ -162,6 +163,7 @@ __global__ void decoder_attn_combine_kernel(const float* __restrict__ ws, float*
   // (softmax branch + CoDA branch) / n_act, n_act = 2 (models.py:140-142).  All keys masked:
   // L == 0 -> NaN, as the reference's softmax over all -inf.
   mix[(int64_t)b * heads * HD + threadIdx.x] = 0.5f * (As / L) + 0.5f * Ac;
+  if (mix_softmax != nullptr) mix_softmax[(int64_t)b * heads * HD + threadIdx.x] = As / L;
   if (c == 0) {
     stats[((int64_t)b * heads + hd) * 2 + 0] = M;
     stats[((int64_t)b * heads + hd) * 2 + 1] = L;
@@ -268,8 +270,8 @@ extern "C" size_t dfd_decoder_attn_workspace(int B, int heads, int d, int splits
 }
 
 extern "C" int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v, int kv_dtype,
-                                    const uint8_t* frame_mask, float* mix, float* stats, void* workspace, int splits,
-                                    int B, int T, int patches, int heads, int d, void* stream) {
+                                    const uint8_t* frame_mask, float* mix, float* mix_softmax, float* stats,
+                                    void* workspace, int splits, int B, int T, int patches, int heads, int d, void* stream) {
   DFD_REQUIRE(q && k && v && frame_mask && mix && stats && workspace, "dfd_decoder_attn_fwd: null pointer");
   DFD_REQUIRE(d == HD, "dfd_decoder_attn_fwd: head dim %d, only 64 is supported", d);
   DFD_REQUIRE(B >= 0 && T > 0 && patches > 0 && heads > 0 && heads * HD <= 1024, "dfd_decoder_attn_fwd: bad shape");
@@ -291,7 +293,7 @@ extern "C" int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v
     hipLaunchKernelGGL((decoder_attn_partial_kernel<bf16_t>), grid, block, lds, st, q, static_cast<const bf16_t*>(k),
                        static_cast<const bf16_t*>(v), frame_mask, ws, splits, T, patches, heads, R);
   DFD_CHECK_LAUNCH("dfd_decoder_attn_fwd(partial)");
-  hipLaunchKernelGGL(decoder_attn_combine_kernel, dim3(B), dim3(heads * HD), 0, st, ws, mix, stats, splits, heads);
+  hipLaunchKernelGGL(decoder_attn_combine_kernel, dim3(B), dim3(heads * HD), 0, st, ws, mix, mix_softmax, stats, splits, heads);
   DFD_CHECK_LAUNCH("dfd_decoder_attn_fwd(combine)");
   return DFD_OK;
 }

@@ -104,63 +104,217 @@ class Decoder(nn.Module):
             vs.append(v.reshape(b * t * p, h * d))
         return torch.stack(ks).contiguous(), torch.stack(vs).contiguous()
 
-    @torch.no_grad()
     def forward(self, kvs, m):
         """kvs: packed (k, v) tensors [L, B*T*P, D] with the positional embedding already added
         (the encoder's export), or the reference's list of dicts.  m: [B, T] bool.
         Returns (task_logits list of [B, out_dim] — NOT yet rescaled, as in the reference — and
-        video_feature [B, D])."""
-        raw, feat, _ = self._forward_impl(kvs, m)
+        video_feature [B, D]).  Differentiable w.r.t. the decoder parameters when grad is enabled."""
+        raw, feat, _ = self.run(kvs, m)
         return raw, feat
 
-    def _forward_impl(self, kvs, m):
-        if isinstance(kvs, (list,)):
+    # ---- plumbing ------------------------------------------------------------------------------
+    def _unpack(self, kvs, m):
+        if isinstance(kvs, list):
             k_all, v_all = self._pack(kvs)
         else:
             k_all, v_all = kvs
         if not k_all.is_cuda:
             raise capi.DfdError("the decoder runs on HIP kernels only: pass device tensors")
-        dev = k_all.device
         B, T = m.shape
-        D, H = self.width, self.heads
-        L = k_all.shape[0]
         S = k_all.shape[1] // B
-        P = S // T
-        assert L == len(self.layer_indices) and S == T * P and k_all.shape[2] == D
-        mask = m.to(device=dev, dtype=torch.uint8).contiguous()
-        f32 = dict(device=dev, dtype=torch.float32)
-        # enough workgroups to fill 256 CUs a few times over, few enough partial states to merge cheaply
-        splits = max(1, min(S // 64, max(1, 768 // max(B, 1))))
-        ws = torch.empty(capi.decoder_attn_workspace_bytes(B, H, 64, splits) // 4, **f32)
-        g = lambda t: t.detach().to(torch.float32).contiguous()
+        assert k_all.shape[0] == len(self.layer_indices) and S % T == 0 and k_all.shape[2] == self.width
+        mask = m.to(device=k_all.device, dtype=torch.uint8).contiguous()
+        return k_all, v_all, mask, B, T, S // T
 
-        x0 = self.class_embedding.detach().to(torch.float32).view(1, D).repeat(B, 1).contiguous()
-        x = torch.empty(B, D, **f32)
-        capi.layernorm(x0, g(self.ln_pre.weight), g(self.ln_pre.bias), x)
-        h = torch.empty(B, D, **f32)
-        q = torch.empty(B, 2 * D, **f32)
-        mix = torch.empty(B, D, **f32)
-        stats = torch.empty(B, H, 2, **f32)
-        u = torch.empty(B, 4 * D, **f32)
-        for i, blk in enumerate(self.transformer.resblocks):
-            capi.layernorm(x, g(blk.ln_1.weight), g(blk.ln_1.bias), h)
-            capi.linear_rows(h, g(blk.attn.in_proj.weight), g(blk.attn.in_proj.bias), q)
-            capi.decoder_attn_fwd(q, k_all[i], v_all[i], mask, mix, stats, ws, splits, B, T, P, H)
-            capi.linear_rows(mix, g(blk.attn.out_proj.weight), g(blk.attn.out_proj.bias), x, capi.EPI_BIAS_RESIDUAL)
-            capi.layernorm(x, g(blk.ln_2.weight), g(blk.ln_2.bias), h)
-            capi.linear_rows(h, g(blk.mlp.c_fc.weight), g(blk.mlp.c_fc.bias), u, capi.EPI_BIAS_QUICKGELU)
-            capi.linear_rows(u, g(blk.mlp.c_proj.weight), g(blk.mlp.c_proj.bias), x, capi.EPI_BIAS_RESIDUAL)
-            aq = self.transformer.augment_query_embeddings
-            if len(aq) > 0 and i != L - 1:
-                # result.append(x) precedes the add in the reference (models.py:263-267); only the
-                # last block's x is read when there is one projection per task (models.py:340-341)
-                x += aq[i].detach().to(torch.float32)
-        feat = torch.empty(B, D, **f32)
+    def _splits(self, B, S):
+        # enough workgroups to fill 256 CUs a few times over, few enough partial states to merge cheaply
+        return max(1, min(S // 64, max(1, 768 // max(B, 1))))
+
+    def run(self, kvs, m):
+        """-> (raw logits list, video_feature, normalised logits list).  With grad enabled and any
+        trainable parameter, goes through `_DecoderFn` so `loss.backward()` reaches the parameters."""
+        k_all, v_all, mask, B, T, P = self._unpack(kvs, m)
+        names = [n for n, p in self.named_parameters()]
+        params = [p for n, p in self.named_parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            out = _DecoderFn.apply(self, k_all, v_all, mask, (B, T, P), names, *params)
+            n = len(self.out_dims)
+            return list(out[1:1 + n]), out[0], list(out[1 + n:1 + 2 * n])
+        w = {n: p.detach() for n, p in zip(names, params)}
+        raws, feat, outs, _ = self._forward_kernels(w, k_all, v_all, mask, B, T, P, save=False)
+        return raws, feat, outs
+
+    # ---- forward on HIP kernels --------------------------------------------------------------
+    def _forward_kernels(self, w, k_all, v_all, mask, B, T, P, save):
+        dev = k_all.device
+        D, H, L = self.width, self.heads, k_all.shape[0]
+        f32 = dict(device=dev, dtype=torch.float32)
+        new = lambda *shape: torch.empty(*shape, **f32)
+        g = lambda name: w[name].to(torch.float32).contiguous()
+        splits = self._splits(B, T * P)
+        ws = new(capi.decoder_attn_workspace_bytes(B, H, 64, splits) // 4)
+        x0 = g("class_embedding").view(1, D).repeat(B, 1).contiguous()
+        x = new(B, D)
+        capi.layernorm(x0, g("ln_pre.weight"), g("ln_pre.bias"), x)
+        saved = dict(x0=x0, blocks=[])
+        h, q, mix, stats, u = new(B, D), new(B, 2 * D), new(B, D), new(B, H, 2), new(B, 4 * D)
+        for i in range(L):
+            pre = f"transformer.resblocks.{i}."
+            if save:  # keep every intermediate of the block for the backward pass
+                h1, q, mix, mix_s, stats = new(B, D), new(B, 2 * D), new(B, D), new(B, D), new(B, H, 2)
+                x_in = x
+                capi.layernorm(x_in, g(pre + "ln_1.weight"), g(pre + "ln_1.bias"), h1)
+                capi.linear_rows(h1, g(pre + "attn.in_proj.weight"), g(pre + "attn.in_proj.bias"), q)
+                capi.decoder_attn_fwd(q, k_all[i], v_all[i], mask, mix, stats, ws, splits, B, T, P, H, mix_softmax=mix_s)
+                x_mid = x_in.clone()
+                capi.linear_rows(mix, g(pre + "attn.out_proj.weight"), g(pre + "attn.out_proj.bias"), x_mid, capi.EPI_BIAS_RESIDUAL)
+                h2, u_pre, uu = new(B, D), new(B, 4 * D), new(B, 4 * D)
+                capi.layernorm(x_mid, g(pre + "ln_2.weight"), g(pre + "ln_2.bias"), h2)
+                capi.linear_rows(h2, g(pre + "mlp.c_fc.weight"), g(pre + "mlp.c_fc.bias"), u_pre)
+                capi.quickgelu(u_pre, uu)
+                x = x_mid.clone()
+                capi.linear_rows(uu, g(pre + "mlp.c_proj.weight"), g(pre + "mlp.c_proj.bias"), x, capi.EPI_BIAS_RESIDUAL)
+                saved["blocks"].append(dict(x_in=x_in, h1=h1, q=q, mix=mix, mix_s=mix_s, stats=stats, x_mid=x_mid, h2=h2,
+                                            u_pre=u_pre, u=uu))
+            else:
+                capi.layernorm(x, g(pre + "ln_1.weight"), g(pre + "ln_1.bias"), h)
+                capi.linear_rows(h, g(pre + "attn.in_proj.weight"), g(pre + "attn.in_proj.bias"), q)
+                capi.decoder_attn_fwd(q, k_all[i], v_all[i], mask, mix, stats, ws, splits, B, T, P, H)
+                capi.linear_rows(mix, g(pre + "attn.out_proj.weight"), g(pre + "attn.out_proj.bias"), x, capi.EPI_BIAS_RESIDUAL)
+                capi.layernorm(x, g(pre + "ln_2.weight"), g(pre + "ln_2.bias"), h)
+                capi.linear_rows(h, g(pre + "mlp.c_fc.weight"), g(pre + "mlp.c_fc.bias"), u, capi.EPI_BIAS_QUICKGELU)
+                capi.linear_rows(u, g(pre + "mlp.c_proj.weight"), g(pre + "mlp.c_proj.bias"), x, capi.EPI_BIAS_RESIDUAL)
+            aq = f"transformer.augment_query_{i}"
+            if aq in w and i != L - 1:
+                # result.append(x) precedes the add in the reference (models.py:263-267); only the last
+                # block's x is read when there is one projection per task (models.py:340-341)
+                x = x + g(aq)
+        feat = new(B, D)
         raws, outs = [], []
         for i, od in enumerate(self.out_dims):
-            raw = torch.empty(B, od, **f32)
-            logits = torch.empty(B, od, **f32)
-            capi.head_fwd(x, g(self.ln_post.weight), g(self.ln_post.bias), g(self.task_projections[i][-1]), feat, raw, logits)
+            raw, logits = new(B, od), new(B, od)
+            capi.head_fwd(x, g("ln_post.weight"), g("ln_post.bias"), g(f"proj{i}x{od}"), feat, raw, logits)
             raws.append(raw)
             outs.append(logits)
-        return raws, feat, outs
+        saved["x_last"] = x
+        saved["feat"] = feat
+        saved["raws"] = raws
+        return raws, feat, outs, saved
+
+    # ---- backward on HIP kernels -------------------------------------------------------------
+    def _backward_kernels(self, w, saved, k_all, v_all, mask, B, T, P, d_feat, d_raws, d_logits):
+        """Gradients of every decoder parameter (dict name -> tensor), given dL/d(video_feature),
+        dL/d(raw logits) and dL/d(normalised logits) (any may be None)."""
+        dev = k_all.device
+        D, H, L = self.width, self.heads, k_all.shape[0]
+        f32 = dict(device=dev, dtype=torch.float32)
+        new = lambda *shape: torch.empty(*shape, **f32)
+        g = lambda name: w[name].to(torch.float32).contiguous()
+        grads = {}
+        xhat = new(B, D)
+
+        def lin_bwd(pre, dy, x_act, want_dx=True):
+            """dy [B,N] -> grads of Linear `pre` (weight [N,K], bias) and, optionally, dx [B,K]."""
+            W = g(pre + "weight")
+            N, K = W.shape
+            dW, db = new(N, K), new(N)
+            capi.linear_rows_bwd_weight(dy, x_act, dW, db)
+            grads[pre + "weight"], grads[pre + "bias"] = dW, db
+            if not want_dx:
+                return None
+            Wt = new(K, N)
+            capi.transpose(W, Wt)
+            dx = new(B, K)
+            capi.linear_rows(dy, Wt, None, dx)
+            return dx
+
+        # ---- head: logits = 5 z/(|z|+eps), z = feat @ proj, feat = ln_post(x_last)
+        feat, x_last = saved["feat"], saved["x_last"]
+        dfeat = d_feat.contiguous().clone() if d_feat is not None else None
+        for i, od in enumerate(self.out_dims):
+            raw = saved["raws"][i]
+            proj = g(f"proj{i}x{od}")
+            dz, dfi, dproj = new(B, od), new(B, D), new(D, od)
+            dl = d_logits[i]
+            if dl is None:  # gradient only through the raw (un-normalised) logits, or none at all
+                dz = d_raws[i].contiguous() if d_raws[i] is not None else torch.zeros(B, od, **f32)
+                capi.head_bwd(raw, torch.zeros(B, od, **f32), proj, feat, dfeat, new(B, od), dfi, dproj)
+                dproj = feat.t().contiguous() @ dz  # rare path (raw logits consumed directly): plain glue
+                dfi = dfi + dz @ proj.t()
+            else:
+                capi.head_bwd(raw, dl.contiguous(), proj, feat, dfeat, dz, dfi, dproj)
+                if d_raws[i] is not None:
+                    dproj = dproj + feat.t().contiguous() @ d_raws[i]
+                    dfi = dfi + d_raws[i] @ proj.t()
+            grads[f"proj{i}x{od}"] = dproj
+            dfeat = dfi
+        if dfeat is None:
+            dfeat = torch.zeros(B, D, **f32)
+        dx = new(B, D)
+        dgam, dbet = new(D), new(D)
+        capi.layernorm_bwd(x_last, g("ln_post.weight"), dfeat, dx, dgam, dbet, xhat)
+        grads["ln_post.weight"], grads["ln_post.bias"] = dgam, dbet
+
+        ws = new(capi.decoder_attn_bwd_workspace_bytes(B, T, H) // 4)
+        has_pos = "positional_embedding" in w
+        dpos_total = torch.zeros(T, D, **f32) if has_pos else None
+        for i in reversed(range(L)):
+            pre = f"transformer.resblocks.{i}."
+            sv = saved["blocks"][i]
+            aq = f"transformer.augment_query_{i}"
+            if aq in w and i != L - 1:
+                grads[aq] = dx.sum(dim=0)  # x_{i+1,in} = x_{i,out} + aq_i
+            # x_out = x_mid + c_proj(u)
+            du = lin_bwd(pre + "mlp.c_proj.", dx, sv["u"])
+            du_pre = new(B, 4 * D)
+            capi.quickgelu(sv["u_pre"], du_pre, du=du)
+            dh2 = lin_bwd(pre + "mlp.c_fc.", du_pre, sv["h2"])
+            dgam, dbet = new(D), new(D)
+            capi.layernorm_bwd(sv["x_mid"], g(pre + "ln_2.weight"), dh2, dx, dgam, dbet, xhat, accumulate_dx=True)
+            grads[pre + "ln_2.weight"], grads[pre + "ln_2.bias"] = dgam, dbet
+            # x_mid = x_in + out_proj(mix)
+            dmix = lin_bwd(pre + "attn.out_proj.", dx, sv["mix"])
+            dq = new(B, 2 * D)
+            dpos = new(T, D) if has_pos else None
+            capi.decoder_attn_bwd(sv["q"], k_all[i], v_all[i], mask, dmix, sv["mix_s"], sv["stats"], dq, dpos, ws, B, T, P, H)
+            if has_pos:
+                dpos_total += dpos
+            dh1 = lin_bwd(pre + "attn.in_proj.", dq, sv["h1"])
+            dgam, dbet = new(D), new(D)
+            capi.layernorm_bwd(sv["x_in"], g(pre + "ln_1.weight"), dh1, dx, dgam, dbet, xhat, accumulate_dx=True)
+            grads[pre + "ln_1.weight"], grads[pre + "ln_1.bias"] = dgam, dbet
+        # x_0 = ln_pre(class_embedding) for every clip
+        dcls_rows = new(B, D)
+        dgam, dbet = new(D), new(D)
+        capi.layernorm_bwd(saved["x0"], g("ln_pre.weight"), dx, dcls_rows, dgam, dbet, xhat)
+        grads["ln_pre.weight"], grads["ln_pre.bias"] = dgam, dbet
+        grads["class_embedding"] = dcls_rows.sum(dim=0)
+        if has_pos:
+            grads["positional_embedding"] = dpos_total.view(T, 1, H, D // H)
+        return grads
+
+
+class _DecoderFn(torch.autograd.Function):
+    """autograd node around the decoder's HIP forward / backward kernels.
+    Outputs: (video_feature, *raw_logits, *normalised_logits)."""
+
+    @staticmethod
+    def forward(ctx, dec, k_all, v_all, mask, dims, names, *params):
+        B, T, P = dims
+        w = {n: p.detach() for n, p in zip(names, params)}
+        raws, feat, outs, saved = dec._forward_kernels(w, k_all, v_all, mask, B, T, P, save=True)
+        ctx.dec, ctx.w, ctx.saved, ctx.dims, ctx.names = dec, w, saved, dims, names
+        ctx.kv = (k_all, v_all, mask)
+        ctx.n_out = len(raws)
+        ctx.req = [p.requires_grad for p in params]
+        return (feat, *raws, *outs)
+
+    @staticmethod
+    def backward(ctx, d_feat, *d_rest):
+        n = ctx.n_out
+        d_raws, d_logits = list(d_rest[:n]), list(d_rest[n:2 * n])
+        k_all, v_all, mask = ctx.kv
+        B, T, P = ctx.dims
+        grads = ctx.dec._backward_kernels(ctx.w, ctx.saved, k_all, v_all, mask, B, T, P, d_feat, d_raws, d_logits)
+        out = [grads.get(nm) if rq else None for nm, rq in zip(ctx.names, ctx.req)]
+        return (None, None, None, None, None, None, *out)

@@ -159,8 +159,10 @@ class Detector(nn.Module):
         if t != self.num_frames and self.decoder.positional_embedding is not None:
             raise RuntimeError(f"The size of tensor a ({t}) must match the size of tensor b ({self.num_frames}) "
                                "at non-singleton dimension 1 (temporal positional embedding)")
+        # the encoder is frozen and runs without autograd (reference models.py:440, :501); the decoder is
+        # differentiable w.r.t. its own parameters
         kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, self.decoder.temporal_pos())
-        _, video_features, task_logits = self.decoder._forward_impl(kv, m)
+        _, video_features, task_logits = self.decoder.run(kv, m)
         features = {}
         if with_video_features:
             features["video"] = video_features

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DFD_ABI_VERSION 1
+#define DFD_ABI_VERSION 2
 
 enum { DFD_F32 = 0, DFD_BF16 = 1 };
 
@@ -98,17 +98,55 @@ int dfd_linear_rows(const float* x, int64_t ldx, const float* W, const float* bi
  *   k, v       kv_dtype [B, S, heads*d]
  *   frame_mask u8 [B, T], S == T * patches
  *   mix        f32 [B, heads*d]
+ *   mix_softmax f32 [B, heads*d] or NULL: the softmax branch alone (Σ a_j v_j), kept for backward
  *   stats      f32 [B, heads, 2] = (row max, sum of exp) of the softmax branch, kept for backward
  *   workspace  f32, at least dfd_decoder_attn_workspace(B, heads, d, splits) bytes. */
 size_t dfd_decoder_attn_workspace(int B, int heads, int d, int splits);
 int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v, int kv_dtype, const uint8_t* frame_mask,
-                         float* mix, float* stats, void* workspace, int splits, int B, int T, int patches,
-                         int heads, int d, void* stream);
+                         float* mix, float* mix_softmax, float* stats, void* workspace, int splits, int B, int T,
+                         int patches, int heads, int d, void* stream);
 
 /* Head: video_feature = LayerNorm(x) (ln_post), z = video_feature @ proj [D, out_dim],
  * logits = 5 z / (‖z‖₂ + 1e-10)  (models.py:342-343, :359, :551-553).  All f32. */
 int dfd_head_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* proj,
                  float* video_feature, float* raw_logits, float* logits, int B, int D, int out_dim, float eps,
+                 void* stream);
+
+/* ---- decoder backward (the encoder is frozen: reference models.py:440, :501; these are the
+ *      gradients `accelerator.backward` produces in the reference train step, trainer.py:157-165) ---- */
+
+/* Gradient of dfd_decoder_attn_fwd w.r.t. its query and, because the exported K/V are
+ * `encoder_kv + temporal positional embedding` (models.py:326-329), w.r.t. that embedding:
+ *   dq   f32 [B, heads, 2*d];  dpos f32 [T, heads*d] = Σ_{clip, patch} (dK + dV), or NULL;
+ *   dk, dv f32 [B, S, heads*d] or NULL: the full key/value gradients (adapter training only);
+ *   dmix, mix_softmax [B, heads*d], stats [B, heads, 2] from the forward;
+ *   workspace >= dfd_decoder_attn_bwd_workspace(B, T, heads, d) bytes. */
+size_t dfd_decoder_attn_bwd_workspace(int B, int T, int heads, int d);
+int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v, int kv_dtype, const uint8_t* frame_mask,
+                         const float* dmix, const float* mix_softmax, const float* stats, float* dq, float* dpos,
+                         float* dk, float* dv, void* workspace, int B, int T, int patches, int heads, int d,
+                         void* stream);
+
+/* dW[N,K] = dyᵀ x, db[N] = Σ_b dy (db may be NULL): weight gradient of dfd_linear_rows. */
+int dfd_linear_rows_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dW, float* db, int B,
+                               int N, int K, void* stream);
+
+/* dst[cols, rows] = src[rows, cols]ᵀ — the data gradient of dfd_linear_rows is dfd_linear_rows on Wᵀ. */
+int dfd_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream);
+
+/* LayerNorm backward over `rows` rows: dx = [dx +] ∂L/∂x (accumulate_dx != 0 adds into dx: the
+ * residual branch), dgamma/dbeta [cols] summed over rows; xhat_ws: rows*cols floats of scratch. */
+int dfd_layernorm_bwd(const float* x, int64_t ldx, const float* gamma, const float* dy, int64_t lddy, float* dx,
+                      int64_t lddx, float* dgamma, float* dbeta, float* xhat_ws, int rows, int cols, float eps,
+                      int accumulate_dx, void* stream);
+
+/* QuickGELU on n elements: du == NULL: out = u·σ(1.702u); otherwise out = du · d/du[u·σ(1.702u)]. */
+int dfd_quickgelu(const float* u, const float* du, float* out, int64_t n, void* stream);
+
+/* Backward of dfd_head_fwd after its LayerNorm: dz = ∂L/∂(raw logits) through 5z/(‖z‖+1e-10),
+ * dfeat = dz·projᵀ (+ dfeat_ext if not NULL), dproj [D, out_dim] = featᵀ dz. */
+int dfd_head_bwd(const float* raw_logits, const float* dlogits, const float* proj, const float* feat,
+                 const float* dfeat_ext, float* dz, float* dfeat, float* dproj, int B, int D, int out_dim,
                  void* stream);
 
 #ifdef __cplusplus

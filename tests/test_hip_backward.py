@@ -1,0 +1,201 @@
+"""GPU parity of the decoder backward (the path's only gradients: the encoder is frozen) through the
+C ABI: kernel by kernel against torch autograd of the CPU oracle, then the whole train-step
+contract (reference src/trainer.py:147-177: forward(train=True) -> mean loss -> backward -> SGD
+momentum 0.95, wd 0.01) against gradients and parameters produced by the reference itself
+(tests/golden)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu
+from tests.cases import build_case, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from dfd_clip_amd import capi as c
+    c.load_library()
+    assert torch.cuda.is_available()
+    return c
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.from_numpy(np.random.default_rng(seed).standard_normal(shape).astype(np.float32) * scale)
+
+
+def close(got, want, atol, rtol=0.0, msg=""):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    err = (got - want).abs()
+    assert torch.isfinite(got).all(), msg
+    assert (err <= atol + rtol * want.abs()).all(), f"{msg}: max err {err.max().item():.3e}, ref scale {want.abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("B,T,P,heads", [(2, 4, 4, 2), (3, 3, 196, 4), (2, 8, 196, 12)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decoder_attention_backward(capi, B, T, P, heads, dtype):
+    D, S = heads * 64, T * P
+    k = rnd(B, S, heads, 64, seed=1).to(dtype).float()
+    v = rnd(B, S, heads, 64, seed=2).to(dtype).float()
+    q = rnd(B, 1, heads, 128, seed=3).requires_grad_(True)
+    pos = torch.zeros(T, 1, heads, 64, requires_grad=True)  # K/V = exported + pos: d/dpos = sum of dK + dV
+    m = torch.ones(B, T, dtype=torch.bool)
+    if B > 1:
+        m[1, T - max(1, T // 4):] = False
+    w = {"p.attn.in_proj.weight": torch.eye(2 * D), "p.attn.in_proj.bias": torch.zeros(2 * D),
+         "p.attn.out_proj.weight": torch.eye(D), "p.attn.out_proj.bias": torch.zeros(D)}
+    kk = (k.view(B, T, P, heads, 64) + pos).flatten(1, 2).requires_grad_(True)
+    vv = (v.view(B, T, P, heads, 64) + pos).flatten(1, 2).requires_grad_(True)
+    kk.retain_grad(), vv.retain_grad()
+    out = ref_cpu.decoder_attention(q.reshape(B, 1, 2 * D), kk, vv, m.repeat_interleave(P, dim=-1), w, "p.", heads, T)
+    dmix = rnd(B, D, seed=4)
+    (out.reshape(B, D) * dmix).sum().backward()
+
+    kd, vd = k.to(dtype).reshape(B, S, D).cuda(), v.to(dtype).reshape(B, S, D).cuda()
+    qd, md = q.detach().reshape(B, 2 * D).cuda(), m.to(torch.uint8).cuda()
+    splits = 2
+    ws = torch.empty(capi.decoder_attn_workspace_bytes(B, heads, 64, splits) // 4, device="cuda")
+    mix, mix_s, stats = torch.empty(B, D, device="cuda"), torch.empty(B, D, device="cuda"), torch.empty(B, heads, 2, device="cuda")
+    capi.decoder_attn_fwd(qd, kd, vd, md, mix, stats, ws, splits, B, T, P, heads, mix_softmax=mix_s)
+    close(mix, out.reshape(B, D), 2e-5, 1e-4, "forward")
+    ws2 = torch.empty(capi.decoder_attn_bwd_workspace_bytes(B, T, heads) // 4, device="cuda")
+    dq, dpos = torch.empty(B, 2 * D, device="cuda"), torch.empty(T, D, device="cuda")
+    dk, dv = torch.empty(B, S, D, device="cuda"), torch.empty(B, S, D, device="cuda")
+    capi.decoder_attn_bwd(qd, kd, vd, md, dmix.cuda(), mix_s, stats, dq, dpos, ws2, B, T, P, heads, dk=dk, dv=dv)
+    close(dq, q.grad.reshape(B, 2 * D), 2e-5, 2e-4, "dq")
+    close(dk, kk.grad.reshape(B, S, D), 2e-6, 2e-4, "dk")
+    close(dv, vv.grad.reshape(B, S, D), 2e-6, 2e-4, "dv")
+    close(dpos, pos.grad.reshape(T, D), 5e-5, 2e-4, "dpos")
+    dq2, dpos2 = torch.empty_like(dq), torch.empty_like(dpos)
+    capi.decoder_attn_bwd(qd, kd, vd, md, dmix.cuda(), mix_s, stats, dq2, dpos2, ws2, B, T, P, heads)  # without dK/dV
+    assert torch.equal(dq, dq2) and torch.equal(dpos, dpos2)
+
+
+@pytest.mark.parametrize("B,N,K", [(2, 8, 128), (16, 1536, 768), (16, 768, 3072), (9, 100, 64)])
+def test_linear_backward(capi, B, N, K):
+    x, w, dy = rnd(B, K, seed=5), rnd(N, K, seed=6, scale=K ** -0.5), rnd(B, N, seed=7)
+    dw, db = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda")
+    capi.linear_rows_bwd_weight(dy.cuda(), x.cuda(), dw, db)
+    close(dw, dy.double().T @ x.double(), 2e-5, 1e-5, "dW")
+    close(db, dy.double().sum(0), 2e-5, 1e-5, "db")
+    wt = torch.empty(K, N, device="cuda")
+    capi.transpose(w.cuda(), wt)
+    assert torch.equal(wt.cpu(), w.T.contiguous())
+    dx = torch.empty(B, K, device="cuda")
+    capi.linear_rows(dy.cuda(), wt, None, dx)
+    close(dx, dy.double() @ w.double(), 2e-5, 1e-5, "dx")
+
+
+@pytest.mark.parametrize("B,D", [(2, 128), (16, 768), (5, 1024)])
+def test_layernorm_and_gelu_backward(capi, B, D):
+    x = (rnd(B, D, seed=8, scale=2.0) + 0.3).requires_grad_(True)
+    g = (1 + 0.1 * rnd(D, seed=9)).requires_grad_(True)
+    b = (0.1 * rnd(D, seed=10)).requires_grad_(True)
+    dy = rnd(B, D, seed=11)
+    (F.layer_norm(x, (D,), g, b, 1e-5) * dy).sum().backward()
+    dx0 = rnd(B, D, seed=12)
+    dx = dx0.clone().cuda()
+    dg, dbt, xh = torch.empty(D, device="cuda"), torch.empty(D, device="cuda"), torch.empty(B, D, device="cuda")
+    capi.layernorm_bwd(x.detach().cuda(), g.detach().cuda(), dy.cuda(), dx, dg, dbt, xh, accumulate_dx=True)
+    close(dx, dx0 + x.grad, 2e-5, 1e-5, "dx (accumulated)")
+    close(dg, g.grad, 2e-5, 1e-5, "dgamma")
+    close(dbt, b.grad, 2e-5, 1e-5, "dbeta")
+    capi.layernorm_bwd(x.detach().cuda(), g.detach().cuda(), dy.cuda(), dx, dg, dbt, xh)
+    close(dx, x.grad, 2e-5, 1e-5, "dx")
+    u = rnd(B, 4 * D, seed=13, scale=2.0).requires_grad_(True)
+    du = rnd(B, 4 * D, seed=14)
+    (ref_cpu.quick_gelu(u) * du).sum().backward()
+    out = torch.empty(B, 4 * D, device="cuda")
+    capi.quickgelu(u.detach().cuda(), out)
+    close(out, ref_cpu.quick_gelu(u), 2e-6, 1e-5, "gelu")
+    capi.quickgelu(u.detach().cuda(), out, du=du.cuda())
+    close(out, u.grad, 2e-6, 1e-5, "gelu'")
+
+
+@pytest.mark.parametrize("B,D,od", [(2, 128, 2), (16, 768, 2), (3, 256, 10)])
+def test_head_backward(capi, B, D, od):
+    feat = rnd(B, D, seed=15).requires_grad_(True)
+    proj = rnd(D, od, seed=16, scale=D ** -0.5).requires_grad_(True)
+    dl, dfe = rnd(B, od, seed=17), rnd(B, D, seed=18)
+    z = feat @ proj
+    ((ref_cpu.normalise_logits(z) * dl).sum() + (feat * dfe).sum()).backward()
+    dz, df, dp = torch.empty(B, od, device="cuda"), torch.empty(B, D, device="cuda"), torch.empty(D, od, device="cuda")
+    capi.head_bwd(z.detach().cuda(), dl.cuda(), proj.detach().cuda(), feat.detach().cuda(), dfe.cuda(), dz, df, dp)
+    close(df, feat.grad, 2e-5, 1e-4, "dfeat")
+    close(dp, proj.grad, 2e-5, 1e-4, "dproj")
+
+
+def make_detector(case, precision):
+    from dfd_clip_amd.detector import Detector
+    det = Detector(case["cfg"], case["T"], None, precision=precision)
+    det.load_state_dict(case["sd"])
+    return det.to("cuda")
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_nopos", "tiny_augq", "small", "vitb16_cfg1"])
+def test_train_step_contract_matches_reference(name):
+    """fp32 path: gradients of every decoder parameter after backward(mean loss), then two SGD steps
+    on the same batch, against the reference's own autograd / optimizer results."""
+    case = build_case(name)
+    g = load_golden(name)
+    det = make_detector(case, "fp32")
+    det.train()
+    x, m, y = case["x"].cuda(), case["m"].cuda(), case["y"].cuda()
+    opt = det.configure_optimizers(0.01)
+    step_losses = []
+    for step in range(2):
+        opt.zero_grad()
+        task_losses, task_logits, other = det(x, [y], m, train=True, single_task=0)
+        loss = task_losses[0].mean() + sum(other.values())
+        loss.backward()
+        if step == 0:
+            checked = 0
+            for pn, p in det.named_parameters():
+                assert (p.grad is None) == pn.startswith("encoder."), pn
+                if p.grad is None:
+                    continue
+                gr = p.grad.detach().float().cpu()
+                if "grad0." + pn in g.files:
+                    want = torch.from_numpy(g["grad0." + pn])
+                    scale = max(want.abs().max().item(), 1e-6)
+                    assert (gr - want).abs().max().item() <= 1e-3 * scale + 2e-7, (pn, (gr - want).abs().max().item(), scale)
+                else:
+                    np.testing.assert_allclose(gr.norm().item(), g["grad0." + pn + ".norm"], rtol=1e-3)
+                    np.testing.assert_allclose(gr.flatten()[:64].numpy(), g["grad0." + pn + ".head"], rtol=2e-3,
+                                               atol=2e-4 * max(float(g["grad0." + pn + ".norm"]), 1e-6) / gr.numel() ** 0.5)
+                checked += 1
+            assert checked > 20
+        step_losses.append(loss.item())
+        opt.step()
+    np.testing.assert_allclose(step_losses, g["step_losses"], atol=2e-4)
+    for pn, p in det.named_parameters():
+        if not p.requires_grad:
+            continue
+        t = p.detach().float().cpu()
+        if "after2." + pn in g.files:
+            np.testing.assert_allclose(t.numpy(), g["after2." + pn], atol=2e-5, rtol=0, err_msg=pn)
+        else:
+            np.testing.assert_allclose(t.flatten()[:64].numpy(), g["after2." + pn + ".head"], atol=2e-5, rtol=0, err_msg=pn)
+
+
+def test_bf16_train_step_gradients_close_to_reference():
+    """bf16 path: same contract; gradients agree with the reference to bf16 accuracy (cosine > 0.999)."""
+    case = build_case("vitb16_cfg1")
+    g = load_golden("vitb16_cfg1")
+    det = make_detector(case, "bf16")
+    det.train()
+    x, m, y = case["x"].cuda(), case["m"].cuda(), case["y"].cuda()
+    task_losses, _, _ = det(x, [y], m, train=True, single_task=0)
+    task_losses[0].mean().backward()
+    params = dict(det.named_parameters())
+    for pn in ("decoder.proj0x2", "decoder.class_embedding", "decoder.ln_post.weight", "decoder.ln_pre.bias",
+               "decoder.transformer.resblocks.0.attn.in_proj.bias", "decoder.transformer.resblocks.5.mlp.c_fc.bias"):
+        got = params[pn].grad.float().cpu().flatten()
+        want = torch.from_numpy(g["grad0." + pn]).flatten()
+        cos = F.cosine_similarity(got, want, dim=0).item()
+        print(f"{pn}: cosine {cos:.6f}")
+        assert cos > 0.999, (pn, cos)
+    pos = params["decoder.positional_embedding"].grad.float().cpu()
+    np.testing.assert_allclose(pos.norm().item(), g["grad0.decoder.positional_embedding.norm"], rtol=2e-2)

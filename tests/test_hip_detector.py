@@ -31,8 +31,9 @@ def test_detector_logits_match_reference(name, precision):
     g = load_golden(name)
     det = make_detector(case, precision)
     x, m, y = case["x"].cuda(), case["m"].cuda(), case["y"].cuda()
-    losses, logits = det(x, [y], m, single_task=0)
-    plog, feats = det.predict(x, m, with_video_features=True)
+    with torch.no_grad():  # the reference's evaluator and inference loops run under no_grad (evaluator.py:50)
+        losses, logits = det(x, [y], m, single_task=0)
+        plog, feats = det.predict(x, m, with_video_features=True)
     tol = FP32_TOL if precision == "fp32" else BF16_TOL
     err = np.abs(logits[0].cpu().numpy() - g["logits"]).max()
     print(f"{name}/{precision}: max |dlogit| = {err:.3e}")
@@ -80,7 +81,8 @@ def test_vitb16_cfg1_matches_reference(precision):
     g = load_golden("vitb16_cfg1")
     det = make_detector(case, precision)
     x, m, y = case["x"].cuda(), case["m"].cuda(), case["y"].cuda()
-    losses, logits = det(x, [y], m, single_task=0)
+    with torch.no_grad():
+        losses, logits = det(x, [y], m, single_task=0)
     err = np.abs(logits[0].cpu().numpy() - g["logits"]).max()
     print(f"vitb16_cfg1/{precision}: max |dlogit| = {err:.3e}")
     assert err <= (FP32_TOL if precision == "fp32" else BF16_TOL)
@@ -106,5 +108,5 @@ def test_frame_chunking_is_bit_identical():
 def test_num_frames_mismatch_raises():
     case = build_case("tiny")
     det = make_detector(case, "fp32")
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError), torch.no_grad():
         det.predict(case["x"][:, :3].cuda(), case["m"][:, :3].cuda())
