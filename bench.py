@@ -2,11 +2,15 @@
 """Headline benchmark: 1-second clips per second through the DFD-CLIP hot path on MI355X.
 
 One step = one pass of the hot path over one batch of synthetic clips that is already
-resident in HBM: `Detector.predict` on x [16, 30, 3, 224, 224] (BASELINE.json configs[1]:
-ViT-B/16, 16 clips x 30 frames, bf16, forward-only inference.py path), per GPU.  With
---gpus N the driver launches one rank per GPU (torch.distributed, backend nccl = RCCL); clips
-are independent, so ranks shard them with no data-path collective except the evaluation
-contract's all-gather of per-clip logits; scaling is weak (16 clips per GPU).
+resident in HBM, x [16, 30, 3, 224, 224] per GPU.  BASELINE.json's metric is "clips/sec ...
+fwd+bwd", so the timed step is the TRAIN step of the reference (src/trainer.py:108-177):
+frozen-encoder forward + decoder forward + decoder backward + SGD(momentum 0.95) step
+(BASELINE configs[2] at N = 1; the encoder has no backward in the reference).  `--mode infer`
+times configs[1] instead (forward-only `Detector.predict`, the inference.py path); the default
+run reports it as `forward_only` next to the headline.  With --gpus N the driver launches one
+rank per GPU (torch.distributed, backend nccl = RCCL); clips are independent, so ranks shard
+them: the only collectives are the gradient all-reduce of the decoder parameters (train) and
+the all-gather of per-clip logits (infer); scaling is weak (16 clips per GPU).
 
 Prints ONE JSON line on rank 0 with the whole-job clips/s plus
   roofline     — the dominant kernel (the MLP c_fc GEMM, M x 3072 x 768 with QuickGELU epilogue):
@@ -42,6 +46,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--frame-chunk", type=int, default=-1, help="frames per encoder pass (-1 = package default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"])
     return ap.parse_args()
 
 
@@ -60,7 +65,7 @@ def build_model(args, device):
     sd = random_state_dict(cfg, args.frames, seed=0)
     det = Detector(cfg, args.frames, None, precision=args.precision)
     det.load_state_dict(sd)
-    det = det.to(device).eval()
+    det = det.to(device)
     if args.frame_chunk >= 0:
         det.encoder.frame_chunk = args.frame_chunk
     return det, cfg, sd, layers
@@ -118,39 +123,64 @@ def main():
     tokens = (res // patch) ** 2 + 1
     M = B * T * tokens
 
+    y = (torch.arange(B, device=device) % 2)
+    from dfd_clip_amd import dist as ddist
+    ddist.broadcast_parameters(det)
+    opt = det.configure_optimizers(0.01 / 25)
+    trainable = [p for p in det.parameters() if p.requires_grad]
+
     @torch.no_grad()
-    def step():
+    def infer_step():
         logits, _ = det.predict(x, m)
         if dist is not None:  # evaluation contract: gather per-clip logits (reference callbacks/metrics.py:98-99)
-            out = [torch.empty_like(logits[0]) for _ in range(world)]
-            dist.all_gather(out, logits[0])
+            ddist.gather_for_metrics(logits[0])
         return logits
+
+    def train_step():
+        det.zero_grad(set_to_none=True)
+        task_losses, _, other = det(x, [y], m, train=True, single_task=0)
+        (task_losses[0].mean() + sum(other.values())).backward()
+        ddist.allreduce_gradients(trainable)  # RCCL over xGMI: one flat all-reduce of the decoder gradients
+        opt.step()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, steps, profile):
+        if profile:  # dominant kernel: c_fc GEMM (M x 4D x D, QuickGELU epilogue); HIP events on the launch stream
+            capi.profile_gemm(epilogue=capi.EPI_BIAS_QUICKGELU)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        spans = capi.profile_gemm_collect() if profile else []
+        if dist is not None:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = tt.item()
+        return dt, spans
+
+    det.train(args.mode == "train")
+    step = train_step if args.mode == "train" else infer_step
     for _ in range(args.warmup):
         step()
-    # dominant kernel: c_fc GEMM (M x 4D x D, QuickGELU epilogue); HIP events on the launch stream
-    capi.profile_gemm(epilogue=capi.EPI_BIAS_QUICKGELU)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    spans = capi.profile_gemm_collect()
-    if dist is not None:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+    dt, spans = timed(step, args.steps, True)
+    fwd_only = None
+    if args.mode == "train":  # informational: BASELINE configs[1], forward-only, outside the headline's timed region
+        det.eval()
+        infer_step()
+        dt_i, _ = timed(infer_step, max(2, args.steps // 2), False)
+        fwd_only = world * B * max(2, args.steps // 2) / dt_i
 
     if rank == 0:
-        flops = 2.0 * M * (4 * width) * width
-        avg_ms = sum(spans) / max(1, len(spans))
-        achieved = flops / (avg_ms * 1e-3) / 1e12 if spans else None
+        # roofline of the dominant kernel: algorithmic FLOPs of each launch / its HIP-event duration
+        avg_ms = sum(ms for ms, _ in spans) / max(1, len(spans))
+        achieved = sum(fl for _, fl in spans) / (sum(ms for ms, _ in spans) * 1e-3) / 1e12 if spans else None
+        launch_m = int(round(spans[0][1] / (2.0 * 4 * width * width))) if spans else M
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
@@ -161,15 +191,20 @@ def main():
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {args.arch} forward-only Detector.predict (inference.py path), "
-                                   f"{B} clips x {T} frames x 3x{res}x{res} per GPU, decode layers {det.layer_indices}, "
-                                   f"random-init weights, inputs resident in HBM",
-                       "clips_per_gpu": B, "frames_per_clip": T, "frame_chunk": det.encoder.frame_chunk},
-            "roofline": {"bound": "mfma", "kernel": "c_fc GEMM + QuickGELU (M=%d, N=%d, K=%d)" % (M, 4 * width, width),
+            "config": {"workload": (f"BASELINE configs[2] (fwd+bwd): {args.arch} train step = frozen-encoder forward + decoder "
+                                    f"forward/backward + SGD step" + (" + RCCL gradient all-reduce" if world > 1 else "")
+                                    if args.mode == "train" else
+                                    f"BASELINE configs[1]: {args.arch} forward-only Detector.predict (inference.py path)")
+                                   + f", {B} clips x {T} frames x 3x{res}x{res} per GPU, decode layers {det.layer_indices}, "
+                                     f"random-init weights, inputs resident in HBM",
+                       "mode": args.mode, "clips_per_gpu": B, "frames_per_clip": T, "frame_chunk": det.encoder.frame_chunk},
+            "roofline": {"bound": "mfma", "kernel": "c_fc GEMM + QuickGELU (M=%d, N=%d, K=%d)" % (launch_m, 4 * width, width),
                          "achieved": round(achieved, 2) if achieved else None, "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,
                          "launches_timed": len(spans), "avg_launch_ms": round(avg_ms, 4)},
         }
+        if fwd_only is not None:
+            line["forward_only"] = {"value": round(fwd_only, 3), "unit": "clips/s", "workload": "BASELINE configs[1]: Detector.predict"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, args)
         print(json.dumps(line), flush=True)

@@ -40,6 +40,9 @@ SIGNATURES = {
                          POINTER(GemmExtra), c_int64, c_int, c_int, c_void_p]),
     "dfd_attention_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dfd_linear_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "dfd_linear_rows_t_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "dfd_linear_rows_t": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
+                                  c_void_p]),
     "dfd_decoder_attn_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dfd_decoder_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -133,8 +136,8 @@ def profile_gemm(epilogue=None):
 
 
 def profile_gemm_collect():
-    """Milliseconds of each timed launch since `profile_gemm`; call after a device sync."""
-    spans = [a.elapsed_time(b) for a, b in _profile["events"]]
+    """(milliseconds, FLOPs) of each timed launch since `profile_gemm`; call after a device sync."""
+    spans = [(a.elapsed_time(b), flops) for a, b, flops in _profile["events"]]
     profile_gemm(None)
     return spans
 
@@ -156,7 +159,7 @@ def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_ex
                                    _DTYPE[c.dtype], _ptr(bias), epilogue, ctypes.byref(extra), M, N, K, _stream()), "dfd_gemm")
     if timed:
         e1.record()
-        _profile["events"].append((e0, e1))
+        _profile["events"].append((e0, e1, 2.0 * M * N * K))
     return c
 
 
@@ -176,6 +179,23 @@ def linear_rows(x, w, bias, y, epilogue=EPI_BIAS):
     N = w.shape[0]
     _check(load_library().dfd_linear_rows(_ptr(x), x.stride(0), _ptr(w), _ptr(bias), _ptr(y), y.stride(0), epilogue, B, N, K,
                                           _stream()), "dfd_linear_rows")
+    return y
+
+
+def linear_rows_t_workspace_bytes(B, N, K):
+    return load_library().dfd_linear_rows_t_workspace(B, N, K)
+
+
+def linear_rows_t(x, wt, bias, y, workspace, epilogue=EPI_BIAS):
+    """y[B,N] = epilogue(x[B,K] @ wt[K,N] + bias): forward with wt = weight^T, data gradient with wt = weight."""
+    _dev(x, wt, bias, y, workspace)
+    assert x.dtype == torch.float32 and wt.dtype == torch.float32 and y.dtype == torch.float32
+    assert x.stride(1) == 1 and y.stride(1) == 1 and wt.is_contiguous()
+    B, K = x.shape
+    N = wt.shape[1]
+    assert wt.shape[0] == K and workspace.numel() * workspace.element_size() >= linear_rows_t_workspace_bytes(B, N, K)
+    _check(load_library().dfd_linear_rows_t(_ptr(x), x.stride(0), _ptr(wt), _ptr(bias), _ptr(y), y.stride(0), epilogue, B, N, K,
+                                            _ptr(workspace), _stream()), "dfd_linear_rows_t")
     return y
 
 

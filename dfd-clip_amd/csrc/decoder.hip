@@ -255,6 +255,95 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
   }
 }
 
+// ---- row-streaming linear: y[b, n] = Σ_k x[b, k] · Wt[k, n] ------------------------------------------
+// Wt is the [K, N] transpose of an nn.Linear weight, so a wave reads 1 KB of one Wt row per
+// instruction (64 lanes x float4, fully coalesced) and the B <= 16 activations x[b, k] of that row
+// are wave-uniform scalars.  K is split over workgroups AND over the 4 waves of a workgroup; the waves'
+// sums are added in LDS, each workgroup writes one slab and linear_t_reduce_kernel adds the slabs in a fixed
+// order (deterministic) and applies bias / QuickGELU / residual.
+constexpr int LT_TILE = 256;  // output columns per workgroup
+
+__global__ __launch_bounds__(256) void linear_t_partial_kernel(const float* __restrict__ x, int64_t ldx,
+                                                               const float* __restrict__ Wt, float* __restrict__ part, int B,
+                                                               int N, int K, int rows_per_wave) {
+  __shared__ f32x4 red[4][16][64];  // [wave][clip][lane]: 64 KB
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = blockIdx.x * LT_TILE + lane * 4;
+  const int k0 = (blockIdx.y * 4 + wave) * rows_per_wave;
+  const int k1 = min(K, k0 + rows_per_wave);
+  f32x4 acc[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (j < N) {
+    const float* wp = Wt + j;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {  // 8 independent 1 KB row reads in flight per wave
+      f32x4 w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const f32x4*>(wp + (int64_t)(k + u) * N);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int b = 0; b < 16; ++b)
+          if (b < B) acc[b] += w[u] * x[(int64_t)b * ldx + k + u];
+    }
+    for (; k < k1; ++k) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wp + (int64_t)k * N);
+#pragma unroll
+      for (int b = 0; b < 16; ++b)
+        if (b < B) acc[b] += w * x[(int64_t)b * ldx + k];
+    }
+  }
+  // add the 4 waves' partial sums in a fixed order; wave w finishes clips 4w .. 4w+3
+#pragma unroll
+  for (int b = 0; b < 16; ++b) red[wave][b][lane] = acc[b];
+  __syncthreads();
+  if (j < N) {
+    float* pp = part + ((int64_t)blockIdx.y * B) * N + j;
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi) {
+      const int b = wave * 4 + bi;
+      if (b < B) *reinterpret_cast<f32x4*>(pp + (int64_t)b * N) = (red[0][b][lane] + red[1][b][lane]) + (red[2][b][lane] + red[3][b][lane]);
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void linear_t_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int64_t ldy, int B, int N, int slabs) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // one float4 of one row
+  const int nq = N >> 2;
+  if (idx >= B * nq) return;
+  const int b = idx / nq, j = (idx % nq) * 4;
+  f32x4 s = bias ? *reinterpret_cast<const f32x4*>(bias + j) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* pp = part + (int64_t)b * N + j;
+  const int64_t stride = (int64_t)B * N;
+  int sl = 0;
+  for (; sl + 8 <= slabs; sl += 8) {  // independent loads first, then a fixed-order sum
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(pp + (sl + u) * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; sl < slabs; ++sl) s += *reinterpret_cast<const f32x4*>(pp + sl * stride);
+  float* yp = y + (int64_t)b * ldy + j;
+  if constexpr (EPI == DFD_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = quick_gelu(s[e]);
+  }
+  if constexpr (EPI == DFD_EPI_BIAS_RESIDUAL) s += *reinterpret_cast<const f32x4*>(yp);
+  *reinterpret_cast<f32x4*>(yp) = s;
+}
+
+// 8 K-rows per wave (32 per workgroup), all 8 row reads of a wave in flight at once
+void linear_t_plan(int N, int K, int* rows_per_wave, int* ksplit) {
+  (void)N;
+  *rows_per_wave = 8;
+  *ksplit = (K + 31) / 32;
+}
+
 int rows_per_block(int heads) {
   const int tpr = heads * 8;
   int R = (256 + tpr - 1) / tpr;
@@ -322,6 +411,51 @@ extern "C" int dfd_linear_rows(const float* x, int64_t ldx, const float* W, cons
       return DFD_ERR_INVALID_ARG;
   }
   DFD_CHECK_LAUNCH("dfd_linear_rows");
+  return DFD_OK;
+}
+
+extern "C" size_t dfd_linear_rows_t_workspace(int B, int N, int K) {
+  if (B <= 0 || N <= 0 || K <= 0) return 0;
+  int rpw, ks;
+  linear_t_plan(N, K, &rpw, &ks);
+  return (size_t)ks * (B < 16 ? B : 16) * N * sizeof(float);
+}
+
+extern "C" int dfd_linear_rows_t(const float* x, int64_t ldx, const float* Wt, const float* bias, float* y, int64_t ldy,
+                                 int epilogue, int B, int N, int K, void* workspace, void* stream) {
+  DFD_REQUIRE(x && Wt && y && workspace, "dfd_linear_rows_t: null pointer");
+  DFD_REQUIRE(B >= 0 && B <= 64 && N > 0 && K > 0 && N % 4 == 0, "dfd_linear_rows_t: bad shape B=%d N=%d K=%d", B, N, K);
+  DFD_REQUIRE(ldx >= K && ldy >= N && ldy % 4 == 0, "dfd_linear_rows_t: bad leading dimensions");
+  DFD_REQUIRE(dfd_aligned16(Wt) && dfd_aligned16(y) && dfd_aligned16(workspace) && (!bias || dfd_aligned16(bias)),
+              "dfd_linear_rows_t: Wt, y, bias and workspace must be 16-byte aligned");
+  if (B == 0) return DFD_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rpw, ks;
+  linear_t_plan(N, K, &rpw, &ks);
+  float* part = static_cast<float*>(workspace);
+  for (int b0 = 0; b0 < B; b0 += 16) {
+    const int bb = B - b0 < 16 ? B - b0 : 16;
+    hipLaunchKernelGGL(linear_t_partial_kernel, dim3((N + LT_TILE - 1) / LT_TILE, ks), dim3(256), 0, st, x + (int64_t)b0 * ldx,
+                       ldx, Wt, part, bb, N, K, rpw);
+    DFD_CHECK_LAUNCH("dfd_linear_rows_t(partial)");
+    const dim3 rg((bb * (N / 4) + 255) / 256), rb(256);
+    float* yb = y + (int64_t)b0 * ldy;
+    switch (epilogue) {
+      case DFD_EPI_BIAS:
+        hipLaunchKernelGGL((linear_t_reduce_kernel<DFD_EPI_BIAS>), rg, rb, 0, st, part, bias, yb, ldy, bb, N, ks);
+        break;
+      case DFD_EPI_BIAS_QUICKGELU:
+        hipLaunchKernelGGL((linear_t_reduce_kernel<DFD_EPI_BIAS_QUICKGELU>), rg, rb, 0, st, part, bias, yb, ldy, bb, N, ks);
+        break;
+      case DFD_EPI_BIAS_RESIDUAL:
+        hipLaunchKernelGGL((linear_t_reduce_kernel<DFD_EPI_BIAS_RESIDUAL>), rg, rb, 0, st, part, bias, yb, ldy, bb, N, ks);
+        break;
+      default:
+        dfd_set_error("dfd_linear_rows_t: epilogue %d unsupported", epilogue);
+        return DFD_ERR_INVALID_ARG;
+    }
+    DFD_CHECK_LAUNCH("dfd_linear_rows_t(reduce)");
+  }
   return DFD_OK;
 }
 

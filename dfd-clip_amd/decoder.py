@@ -76,6 +76,7 @@ class Decoder(nn.Module):
             name = f"proj{i}x{od}"
             setattr(self, name, nn.Parameter(scale * torch.randn(width, od)))
             self.task_projections.append([getattr(self, name)])
+        self._wt_cache = {}  # name -> (parameter version, transposed f32 copy) for the row-streaming linear kernel
         # decoder blocks start from the encoder layer they read (models.py:226-229)
         for b, l in enumerate(self.layer_indices):
             src, dst = enc.transformer.resblocks[l], self.transformer.resblocks[b]
@@ -126,6 +127,25 @@ class Decoder(nn.Module):
         mask = m.to(device=k_all.device, dtype=torch.uint8).contiguous()
         return k_all, v_all, mask, B, T, S // T
 
+    def _wt(self, name, w):
+        """Transposed [K, N] copy of Linear weight `name`, refreshed when the parameter changed (its
+        autograd version counter moves on optimizer.step / load_state_dict / .to())."""
+        p = w[name]
+        key = (p._version, p.data_ptr(), p.device)
+        hit = self._wt_cache.get(name)
+        if hit is None or hit[0] != key:
+            src = p.to(torch.float32).contiguous()
+            dst = torch.empty(src.shape[1], src.shape[0], device=src.device, dtype=torch.float32)
+            capi.transpose(src, dst)
+            self._wt_cache[name] = hit = (key, dst)
+        return hit[1]
+
+    def _lin_ws(self, B, dev):
+        D = self.width
+        shapes = [(2 * D, D), (D, 2 * D), (D, D), (4 * D, D), (D, 4 * D)]
+        nbytes = max(capi.linear_rows_t_workspace_bytes(B, n, k) for n, k in shapes)
+        return torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+
     def _splits(self, B, S):
         # enough workgroups to fill 256 CUs a few times over, few enough partial states to merge cheaply
         return max(1, min(S // 64, max(1, 768 // max(B, 1))))
@@ -153,6 +173,11 @@ class Decoder(nn.Module):
         g = lambda name: w[name].to(torch.float32).contiguous()
         splits = self._splits(B, T * P)
         ws = new(capi.decoder_attn_workspace_bytes(B, H, 64, splits) // 4)
+        lws = self._lin_ws(B, dev)
+
+        def lin(x_, pre_, y_, epi=capi.EPI_BIAS):
+            capi.linear_rows_t(x_, self._wt(pre_ + "weight", w), g(pre_ + "bias"), y_, lws, epi)
+
         x0 = g("class_embedding").view(1, D).repeat(B, 1).contiguous()
         x = new(B, D)
         capi.layernorm(x0, g("ln_pre.weight"), g("ln_pre.bias"), x)
@@ -164,26 +189,26 @@ class Decoder(nn.Module):
                 h1, q, mix, mix_s, stats = new(B, D), new(B, 2 * D), new(B, D), new(B, D), new(B, H, 2)
                 x_in = x
                 capi.layernorm(x_in, g(pre + "ln_1.weight"), g(pre + "ln_1.bias"), h1)
-                capi.linear_rows(h1, g(pre + "attn.in_proj.weight"), g(pre + "attn.in_proj.bias"), q)
+                lin(h1, pre + "attn.in_proj.", q)
                 capi.decoder_attn_fwd(q, k_all[i], v_all[i], mask, mix, stats, ws, splits, B, T, P, H, mix_softmax=mix_s)
                 x_mid = x_in.clone()
-                capi.linear_rows(mix, g(pre + "attn.out_proj.weight"), g(pre + "attn.out_proj.bias"), x_mid, capi.EPI_BIAS_RESIDUAL)
+                lin(mix, pre + "attn.out_proj.", x_mid, capi.EPI_BIAS_RESIDUAL)
                 h2, u_pre, uu = new(B, D), new(B, 4 * D), new(B, 4 * D)
                 capi.layernorm(x_mid, g(pre + "ln_2.weight"), g(pre + "ln_2.bias"), h2)
-                capi.linear_rows(h2, g(pre + "mlp.c_fc.weight"), g(pre + "mlp.c_fc.bias"), u_pre)
+                lin(h2, pre + "mlp.c_fc.", u_pre)
                 capi.quickgelu(u_pre, uu)
                 x = x_mid.clone()
-                capi.linear_rows(uu, g(pre + "mlp.c_proj.weight"), g(pre + "mlp.c_proj.bias"), x, capi.EPI_BIAS_RESIDUAL)
+                lin(uu, pre + "mlp.c_proj.", x, capi.EPI_BIAS_RESIDUAL)
                 saved["blocks"].append(dict(x_in=x_in, h1=h1, q=q, mix=mix, mix_s=mix_s, stats=stats, x_mid=x_mid, h2=h2,
                                             u_pre=u_pre, u=uu))
             else:
                 capi.layernorm(x, g(pre + "ln_1.weight"), g(pre + "ln_1.bias"), h)
-                capi.linear_rows(h, g(pre + "attn.in_proj.weight"), g(pre + "attn.in_proj.bias"), q)
+                lin(h, pre + "attn.in_proj.", q)
                 capi.decoder_attn_fwd(q, k_all[i], v_all[i], mask, mix, stats, ws, splits, B, T, P, H)
-                capi.linear_rows(mix, g(pre + "attn.out_proj.weight"), g(pre + "attn.out_proj.bias"), x, capi.EPI_BIAS_RESIDUAL)
+                lin(mix, pre + "attn.out_proj.", x, capi.EPI_BIAS_RESIDUAL)
                 capi.layernorm(x, g(pre + "ln_2.weight"), g(pre + "ln_2.bias"), h)
-                capi.linear_rows(h, g(pre + "mlp.c_fc.weight"), g(pre + "mlp.c_fc.bias"), u, capi.EPI_BIAS_QUICKGELU)
-                capi.linear_rows(u, g(pre + "mlp.c_proj.weight"), g(pre + "mlp.c_proj.bias"), x, capi.EPI_BIAS_RESIDUAL)
+                lin(h, pre + "mlp.c_fc.", u, capi.EPI_BIAS_QUICKGELU)
+                lin(u, pre + "mlp.c_proj.", x, capi.EPI_BIAS_RESIDUAL)
             aq = f"transformer.augment_query_{i}"
             if aq in w and i != L - 1:
                 # result.append(x) precedes the add in the reference (models.py:263-267); only the last
@@ -212,6 +237,7 @@ class Decoder(nn.Module):
         g = lambda name: w[name].to(torch.float32).contiguous()
         grads = {}
         xhat = new(B, D)
+        lws = self._lin_ws(B, dev)
 
         def lin_bwd(pre, dy, x_act, want_dx=True):
             """dy [B,N] -> grads of Linear `pre` (weight [N,K], bias) and, optionally, dx [B,K]."""
@@ -222,10 +248,8 @@ class Decoder(nn.Module):
             grads[pre + "weight"], grads[pre + "bias"] = dW, db
             if not want_dx:
                 return None
-            Wt = new(K, N)
-            capi.transpose(W, Wt)
             dx = new(B, K)
-            capi.linear_rows(dy, Wt, None, dx)
+            capi.linear_rows_t(dy, W, None, dx, lws)  # dx = dy @ W: the weight [N, K] is already "K-major" for this product
             return dx
 
         # ---- head: logits = 5 z/(|z|+eps), z = feat @ proj, feat = ln_post(x_last)

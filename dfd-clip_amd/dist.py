@@ -1,0 +1,89 @@
+"""Multi-GPU plumbing: one process per GPU over `torch.distributed` (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).
+
+Clips are independent through the whole path, so ranks shard the batch and the forward has no
+exchange step.  The reference's cross-rank traffic is Accelerate/DDP: the
+gradient all-reduce of the trainable (decoder) parameters after each backward (C1,
+`src/trainer.py:157-165`), the all-gather of per-clip outputs for metrics with the padded
+tail dropped (C2/C3, `src/callbacks/metrics.py:98-99`, `inference.py:147-149`), the initial
+parameter broadcast and barriers (C4).  Here they are three explicit calls.
+
+`allreduce_gradients` sends ONE flat fp32 buffer (156 MB for ViT-B/16's decoder): xGMI is
+point-to-point, 7 links per GPU, so a single large collective that RCCL can spread over every
+link beats the per-bucket pattern DDP would issue; the encoder forward of the next micro-batch
+does not depend on it, and it is ~1 % of a step.
+"""
+import torch
+import torch.distributed as dist
+from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def broadcast_parameters(module, src=0):
+    """Make every rank start from rank `src`'s parameters and buffers (DDP does this at wrap time)."""
+    if world_size() == 1:
+        return
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    if not tensors:
+        return
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for group in by_dtype.values():
+        flat = _flatten_dense_tensors(group)
+        dist.broadcast(flat, src)
+        for t, f in zip(group, _unflatten_dense_tensors(flat, group)):
+            t.copy_(f)
+
+
+def allreduce_gradients(params):
+    """Average `.grad` of the given parameters over ranks, in place, with one flat all-reduce.
+    Parameters without a gradient on this rank contribute zeros (DDP's find_unused_parameters)."""
+    n = world_size()
+    params = [p for p in params if p.requires_grad]
+    if n == 1 or not params:
+        return
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    grads = [p.grad for p in params]
+    flat = _flatten_dense_tensors(grads)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(n)
+    for g, f in zip(grads, _unflatten_dense_tensors(flat, grads)):
+        g.copy_(f)
+
+
+def gather_for_metrics(tensors, valid=None):
+    """All-gather a tuple of per-sample tensors (same leading size on every rank) along dim 0 in
+    rank order.  `valid`: number of real samples this rank holds (the rest is padding added to keep
+    shapes equal — the duplicated tail the reference drops after gathering); defaults to all."""
+    n = world_size()
+    single = not isinstance(tensors, (tuple, list))
+    ts = [tensors] if single else list(tensors)
+    if n == 1:
+        out = [t if valid is None else t[:valid] for t in ts]
+        return out[0] if single else tuple(out)
+    dev = ts[0].device
+    cnt = torch.tensor([ts[0].shape[0] if valid is None else valid], device=dev, dtype=torch.int64)
+    counts = [torch.zeros_like(cnt) for _ in range(n)]
+    dist.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    out = []
+    for t in ts:
+        parts = [torch.empty_like(t) for _ in range(n)]
+        dist.all_gather(parts, t.contiguous())
+        out.append(torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0))
+    return out[0] if single else tuple(out)
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()

@@ -91,6 +91,15 @@ int dfd_attention_fwd(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out
 int dfd_linear_rows(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t ldy,
                     int epilogue, int B, int N, int K, void* stream);
 
+/* Same product from the TRANSPOSED weight Wt [K, N] (row-major): y[B,N] = epilogue(x[B,K] · Wt + bias).
+ * Rows of Wt stream fully coalesced and the activations are wave-uniform scalars, so this is the fast
+ * form for both the forward (Wt = weightᵀ, kept by the host and refreshed after each optimizer step)
+ * and the data gradient (dx = dy · W: pass the weight itself as "Wt").  Deterministic (fixed-order
+ * slab reduction).  N % 4 == 0; workspace >= dfd_linear_rows_t_workspace(B, N, K) bytes. */
+size_t dfd_linear_rows_t_workspace(int B, int N, int K);
+int dfd_linear_rows_t(const float* x, int64_t ldx, const float* Wt, const float* bias, float* y, int64_t ldy,
+                      int epilogue, int B, int N, int K, void* workspace, void* stream);
+
 /* Decoder cross-attention of ONE query per clip over S = T*P exported keys/values, two branches
  * averaged (models.py:136-146): softmax(q_s·k/√d) and tanh(q_c·k/√d)·2σ(−‖q_c−k‖₁/√d); keys of padded
  * frames (frame_mask[b,t] == 0) get weight 0 in both (models.py:104, :124).

@@ -200,3 +200,25 @@ def test_head(capi, B, D, od):
     assert_close(raw, z, 2e-5, 1e-5, "raw logits")
     assert_close(logits, ref_cpu.normalise_logits(z), 5e-5, 1e-5, "logits")
     assert_close(logits.norm(dim=-1), torch.full((B,), 5.0), 1e-4, msg="norm 5")
+
+
+@pytest.mark.parametrize("B,N,K", [(1, 8, 128), (2, 256, 128), (16, 1536, 768), (16, 768, 3072), (16, 3072, 768), (9, 100, 64), (20, 768, 768)])
+def test_linear_rows_t(capi, B, N, K):
+    """Row-streaming form on the transposed weight: same results as x @ W^T + b, all three epilogues."""
+    x, w, b = rnd(B, K, seed=28), rnd(N, K, seed=29, scale=K ** -0.5), rnd(N, seed=30, scale=0.1)
+    ref = x.double() @ w.double().T + b.double()
+    wt = w.T.contiguous().cuda()
+    ws = torch.empty(capi.linear_rows_t_workspace_bytes(B, N, K) // 4, device="cuda")
+    y = torch.empty(B, N, device="cuda")
+    capi.linear_rows_t(x.cuda(), wt, b.cuda(), y, ws)
+    assert_close(y, ref, 2e-5, 1e-5, "bias")
+    capi.linear_rows_t(x.cuda(), wt, b.cuda(), y, ws, capi.EPI_BIAS_QUICKGELU)
+    assert_close(y, ref * torch.sigmoid(1.702 * ref), 2e-5, 1e-5, "quickgelu")
+    y0 = rnd(B, N, seed=31)
+    y = y0.clone().cuda()
+    capi.linear_rows_t(x.cuda(), wt, None, y, ws, capi.EPI_BIAS_RESIDUAL)
+    assert_close(y, y0.double() + ref - b.double(), 2e-5, 1e-5, "residual, no bias")
+    y2 = torch.empty(B, N, device="cuda")
+    capi.linear_rows_t(x.cuda(), wt, b.cuda(), y2, ws)
+    capi.linear_rows_t(x.cuda(), wt, b.cuda(), y, ws)
+    assert torch.equal(y, y2)  # deterministic
