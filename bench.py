@@ -187,7 +187,7 @@ def main():
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         line = {
-            "metric": "1-sec clips/sec (30x224x224 frames) ViT-B/16", "value": round(world * B * args.steps / dt, 3),
+            "metric": f"1-sec clips/sec (30x224x224 frames) {args.arch}", "value": round(world * B * args.steps / dt, 3),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",

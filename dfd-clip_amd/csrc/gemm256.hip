@@ -21,8 +21,9 @@
 //   * the product is formed transposed (W fragment as the MFMA A operand), so a lane ends up
 //     with 4 consecutive output columns of one row: the fused epilogues store 8 B (bf16) or
 //     read-modify-write 16 B (f32 residual stream) per lane per fragment;
-//   * workgroup ids are remapped so that each XCD (own L2) walks a contiguous run of tiles,
-//     N fastest: the 256-row A panel is shared from L2 by the N tiles of one panel.
+//   * workgroup ids are remapped so that each XCD (own L2) walks a contiguous run of tiles, ordered
+//     in column groups of <= 6 tiles (panel major inside a group): the A panel is shared from L2 by
+//     the group's column tiles and the group's slice of W stays L2-resident across panels.
 // Rows beyond M are clamped on load and masked on store; N % 256 == 0, K % 64 == 0, K >= 128.
 #include <type_traits>
 
@@ -89,7 +90,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+  // Tile order inside the remapped id: column GROUPS of at most 6 tiles, and inside a group row panel
+  // major / column minor.  An XCD's contiguous run of ids then stays inside one group for a long time:
+  // the group's slice of W (<= 6 x 393 KB at K = 768) stays resident in that XCD's 4 MB L2 while the
+  // A panels stream through, instead of all of W being re-fetched every ~3 panels.
+  const int ngroups = (tiles_n + 5) / 6;
+  const int gcols = (tiles_n + ngroups - 1) / ngroups;     // columns per (full) group
+  const int tiles_m_all = nwg / tiles_n;
+  int grp = wg / (tiles_m_all * gcols);
+  grp = grp < ngroups - 1 ? grp : ngroups - 1;
+  const int rem = wg - grp * tiles_m_all * gcols;
+  const int cols_here = min(gcols, tiles_n - grp * gcols);
+  const int tile_m = rem / cols_here, tile_n = grp * gcols + (rem - tile_m * cols_here);
   const int64_t m0 = (int64_t)tile_m * TM;
   const int n0 = tile_n * TN;
 

@@ -24,6 +24,7 @@ ARCHS = {
     # test-only shapes: every layout rule of the real model at a fraction of the size
     "tiny": (32, 16, 128, 2, 2, 64),
     "small": (224, 16, 256, 3, 4, 64),
+    "small14": (224, 14, 128, 2, 2, 64),  # ViT-L/14's token geometry: 14x14 patches (K = 588), 257 tokens
 }
 
 

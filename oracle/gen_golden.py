@@ -125,6 +125,7 @@ CASES = {
     "tiny_nopos": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], op_mode__temporal_position=0), "light"),
     "tiny_augq": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], op_mode__aug_query=1), "light"),
     "small": ("small", 2, 3, dict(decode_mode="index", decode_indices=[1, 2]), "medium"),
+    "small14": ("small14", 2, 3, dict(decode_mode="index", decode_indices=[0, 1]), "medium"),
     "vitb16_cfg1": ("ViT-B/16", 2, 8, dict(decode_mode="index", decode_indices=[6, 7, 8, 9, 10, 11]), "slices"),
 }
 

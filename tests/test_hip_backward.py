@@ -134,7 +134,7 @@ def make_detector(case, precision):
     return det.to("cuda")
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_nopos", "tiny_augq", "small", "vitb16_cfg1"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_nopos", "tiny_augq", "small", "small14", "vitb16_cfg1"])
 def test_train_step_contract_matches_reference(name):
     """fp32 path: gradients of every decoder parameter after backward(mean loss), then two SGD steps
     on the same batch, against the reference's own autograd / optimizer results."""

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-3
 BF16_TOL = 5e-2
-SUPPORTED = ["tiny", "tiny_stride", "tiny_nopos", "tiny_augq", "small"]
+SUPPORTED = ["tiny", "tiny_stride", "tiny_nopos", "tiny_augq", "small", "small14"]
 
 
 def make_detector(case, precision):
