@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--frame-chunk", type=int, default=-1, help="frames per encoder pass (-1 = package default)")
+    ap.add_argument("--streams", type=int, default=-1, help="HIP streams for independent frame chunks (-1 = package default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     return ap.parse_args()
@@ -68,6 +69,8 @@ def build_model(args, device):
     det = det.to(device)
     if args.frame_chunk >= 0:
         det.encoder.frame_chunk = args.frame_chunk
+    if args.streams >= 0:
+        det.encoder.streams = args.streams
     return det, cfg, sd, layers
 
 
@@ -177,10 +180,20 @@ def main():
         fwd_only = world * B * max(2, args.steps // 2) / dt_i
 
     if rank == 0:
-        # roofline of the dominant kernel: algorithmic FLOPs of each launch / its HIP-event duration
-        avg_ms = sum(ms for ms, _ in spans) / max(1, len(spans))
-        achieved = sum(fl for _, fl in spans) / (sum(ms for ms, _ in spans) * 1e-3) / 1e12 if spans else None
-        launch_m = int(round(spans[0][1] / (2.0 * 4 * width * width))) if spans else M
+        # roofline of the dominant kernel: algorithmic FLOPs of its launches / the time the kernel was running.
+        # Frame chunks run on two streams, so launches can overlap each other and other kernels: the
+        # denominator is the UNION of the launches' HIP-event intervals (a lower bound on the kernel's rate).
+        busy, cur_s, cur_e = 0.0, None, None
+        for st_ms, en_ms, _ in sorted(spans):
+            if cur_e is None or st_ms > cur_e:
+                busy += (cur_e - cur_s) if cur_e is not None else 0.0
+                cur_s, cur_e = st_ms, en_ms
+            else:
+                cur_e = max(cur_e, en_ms)
+        busy += (cur_e - cur_s) if cur_e is not None else 0.0
+        avg_ms = busy / max(1, len(spans))
+        achieved = sum(fl for _, _, fl in spans) / (busy * 1e-3) / 1e12 if spans else None
+        launch_m = int(round(spans[0][2] / (2.0 * 4 * width * width))) if spans else M
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
@@ -197,7 +210,8 @@ def main():
                                     f"BASELINE configs[1]: {args.arch} forward-only Detector.predict (inference.py path)")
                                    + f", {B} clips x {T} frames x 3x{res}x{res} per GPU, decode layers {det.layer_indices}, "
                                      f"random-init weights, inputs resident in HBM",
-                       "mode": args.mode, "clips_per_gpu": B, "frames_per_clip": T, "frame_chunk": det.encoder.frame_chunk},
+                       "mode": args.mode, "clips_per_gpu": B, "frames_per_clip": T, "frame_chunk": det.encoder.frame_chunk,
+                       "streams": det.encoder.streams},
             "roofline": {"bound": "mfma", "kernel": "c_fc GEMM + QuickGELU (M=%d, N=%d, K=%d)" % (launch_m, 4 * width, width),
                          "achieved": round(achieved, 2) if achieved else None, "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,

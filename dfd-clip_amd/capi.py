@@ -125,7 +125,7 @@ def patchify(frames, out, res, patch):
     return out
 
 
-_profile = {"epilogue": None, "events": []}
+_profile = {"epilogue": None, "events": [], "base": None}
 
 
 def profile_gemm(epilogue=None):
@@ -133,11 +133,17 @@ def profile_gemm(epilogue=None):
     the launch stream around the kernel (bench.py's roofline leg).  None switches it off."""
     _profile["epilogue"] = epilogue
     _profile["events"] = []
+    _profile["base"] = None
+    if epilogue is not None:
+        _profile["base"] = torch.cuda.Event(enable_timing=True)
+        _profile["base"].record()
 
 
 def profile_gemm_collect():
-    """(milliseconds, FLOPs) of each timed launch since `profile_gemm`; call after a device sync."""
-    spans = [(a.elapsed_time(b), flops) for a, b, flops in _profile["events"]]
+    """(start_ms, end_ms, FLOPs) of each timed launch since `profile_gemm`, on one time base (launches
+    may sit on different streams and overlap); call after a device sync."""
+    base = _profile["base"]
+    spans = [(base.elapsed_time(a), base.elapsed_time(b), flops) for a, b, flops in _profile["events"]]
     profile_gemm(None)
     return spans
 

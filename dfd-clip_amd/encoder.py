@@ -23,6 +23,8 @@ epilogue: `[N*P, D]` per selected layer, CLS row dropped, temporal positional em
 (reference `src/models.py:505-509`, `:326-334`), and skips the work of the last selected
 layer that cannot reach any exported tensor.
 """
+import contextlib
+
 import torch
 from torch import nn
 
@@ -93,7 +95,12 @@ class VisionTransformer(nn.Module):
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
         self._prepared = None
         self._ws = {}
-        self.frame_chunk = 0  # 0 = whole batch in one pass
+        self.frame_chunk = 0  # frames per pass; 0 = the batch split evenly over `streams`
+        # independent frame chunks can run round-robin on several HIP streams so one chunk's kernels fill the
+        # tails of another's (measured on MI355X, B16xT30: 2 streams +3 %, 3-4 streams lose); default 1
+        # keeps per-kernel timings meaningful
+        self.streams = 1
+        self._side_streams = []
 
     # ---- derived device-side operands ---------------------------------------------------
     @property
@@ -143,10 +150,10 @@ class VisionTransformer(nn.Module):
         self._prepared = p
         return p
 
-    def _workspace(self, n, keep_layers):
+    def _workspace(self, n, keep_layers, slot=0):
         """Activation buffers for n frames.  Rows are padded to a multiple of 256 so tiled kernels
         never read out of bounds; pad rows hold zeros/garbage that is never stored to real rows."""
-        key = (n, self.precision, keep_layers)
+        key = (n, self.precision, keep_layers, slot)
         ws = self._ws.get(key)
         if ws is None:
             dev = self.class_embedding.device
@@ -161,7 +168,7 @@ class VisionTransformer(nn.Module):
                 mix=torch.zeros(Mp, D, device=dev, dtype=act), u=torch.zeros(Mp, 4 * D, device=dev, dtype=act),
                 patches=torch.zeros(Pp, kpad, device=dev, dtype=act),
                 qkv=[torch.zeros(Mp, 3 * D, device=dev, dtype=act) for _ in range(keep_layers)])
-            if len(self._ws) > 4:
+            if len(self._ws) > 6:
                 self._ws.clear()
             self._ws[key] = ws
         return ws
@@ -244,18 +251,34 @@ class VisionTransformer(nn.Module):
             k_out, v_out = out
         last = max(layer_indices)
         slot = {l: i for i, l in enumerate(layer_indices)}
-        chunk = self.frame_chunk if self.frame_chunk > 0 else n
+        clips = n // num_frames
+        chunk = self.frame_chunk if self.frame_chunk > 0 else -(-clips // max(1, self.streams)) * num_frames
         chunk = max(num_frames, chunk // num_frames * num_frames)  # whole clips keep (frame % T) aligned
-        for f0 in range(0, n, chunk):
+        starts = list(range(0, n, chunk))
+        # chunks are independent: with `streams` > 1 they are issued round-robin on side streams, so one
+        # chunk's kernels fill the idle CUs of another chunk's kernel tails (e.g. out_proj = 4.3 tile waves)
+        n_str = min(self.streams, len(starts))
+        if n_str > 1:
+            cur = torch.cuda.current_stream()
+            if len(self._side_streams) < n_str:
+                self._side_streams = [torch.cuda.Stream() for _ in range(n_str)]
+            for st in self._side_streams[:n_str]:
+                st.wait_stream(cur)
+        for ci, f0 in enumerate(starts):
             nf = min(chunk, n - f0)
-            ws = self._workspace(nf, 1)
-            qkv = ws["qkv"][0]
-            M = nf * tok
-            self._embed(frames[f0:f0 + nf], ws, p)
-            for l in range(last + 1):
-                exp = None
-                if l in slot:
-                    i = slot[l]
-                    exp = (k_out[i, f0 * P:(f0 + nf) * P], v_out[i, f0 * P:(f0 + nf) * P], temporal_pos, num_frames)
-                self._block(ws, p["blocks"][l], qkv, M, nf, kv_only=(l == last), export=exp)
+            ctx = torch.cuda.stream(self._side_streams[ci % n_str]) if n_str > 1 else contextlib.nullcontext()
+            with ctx:
+                ws = self._workspace(nf, 1, slot=(ci % n_str) if n_str > 1 else 0)
+                qkv = ws["qkv"][0]
+                M = nf * tok
+                self._embed(frames[f0:f0 + nf], ws, p)
+                for l in range(last + 1):
+                    exp = None
+                    if l in slot:
+                        i = slot[l]
+                        exp = (k_out[i, f0 * P:(f0 + nf) * P], v_out[i, f0 * P:(f0 + nf) * P], temporal_pos, num_frames)
+                    self._block(ws, p["blocks"][l], qkv, M, nf, kv_only=(l == last), export=exp)
+        if n_str > 1:
+            for st in self._side_streams[:n_str]:
+                cur.wait_stream(st)
         return k_out, v_out
