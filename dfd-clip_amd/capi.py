@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
 
 F32, BF16 = 0, 1
-EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT = range(5)
+EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT, EPI_RESIDUAL_POS = range(6)
 ABI_VERSION = 2
 
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
@@ -38,6 +38,7 @@ SIGNATURES = {
     "dfd_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dfd_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int,
                          POINTER(GemmExtra), c_int64, c_int, c_int, c_void_p]),
+    "dfd_adapter_norm_gelu": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dfd_attention_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dfd_linear_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "dfd_linear_rows_t_workspace": (c_size_t, [c_int, c_int, c_int]),
@@ -167,6 +168,15 @@ def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_ex
         e1.record()
         _profile["events"].append((e0, e1, 2.0 * M * N * K))
     return c
+
+
+def adapter_norm_gelu(a, y, weight, bias, frames, patches, x, joint, eps=1e-5):
+    """y = GELU(LayerNorm(a)) on [frames, patches, x]; joint: statistics over (patches, x), else per row."""
+    _dev(a, y, weight, bias)
+    assert a.dtype == y.dtype and a.is_contiguous() and y.is_contiguous() and weight.is_contiguous() and bias.is_contiguous()
+    _check(load_library().dfd_adapter_norm_gelu(_ptr(a), _ptr(y), _DTYPE[a.dtype], _ptr(weight), _ptr(bias), frames, patches, x,
+                                                int(joint), eps, _stream()), "dfd_adapter_norm_gelu")
+    return y
 
 
 def attention_fwd(qkv, out, n_frames, tokens, heads, head_dim=64):

@@ -41,6 +41,11 @@ __device__ __forceinline__ void epilogue_elem(const GemmArgs& a, int64_t m, int 
     float* c = static_cast<float*>(a.C);
     c[(frame * a.tokens + 1 + p) * a.ldc + n] = acc + a.pos[(int64_t)(1 + p) * a.N + n];
     if (p == 0) c[(frame * a.tokens) * a.ldc + n] = a.cls[n] + a.pos[n];
+  } else if constexpr (EPI == DFD_EPI_RESIDUAL_POS) {
+    const int64_t frame = m / (a.tokens - 1);
+    const float p = a.pos ? a.pos[(frame % a.frames_per_clip) * a.N + n] : 0.f;
+    CT* c = static_cast<CT*>(a.C) + m * a.ldc + n;
+    *c = from_f32<CT>(to_f32(*c) + acc + p);
   } else if constexpr (EPI == DFD_EPI_QKV_EXPORT) {
     const float v = acc + (a.bias ? a.bias[n] : 0.f);
     store_c<CT>(a.C, m * a.ldc + n, v);
@@ -179,6 +184,7 @@ int launch_gemm128(const GemmArgs& a, int epi, hipStream_t st) {
     EPI_CASE(DFD_EPI_BIAS)
     EPI_CASE(DFD_EPI_BIAS_QUICKGELU)
     EPI_CASE(DFD_EPI_QKV_EXPORT)
+    EPI_CASE(DFD_EPI_RESIDUAL_POS)
     default:
       if constexpr (sizeof(CT) == 4) {
         switch (epi) {
@@ -227,6 +233,10 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
     DFD_REQUIRE(M % extra->tokens == 0, "dfd_gemm: QKV_EXPORT M=%lld is not a whole number of frames", (long long)M);
     DFD_REQUIRE(!extra->k_export == !extra->v_export, "dfd_gemm: QKV_EXPORT needs both k_export and v_export or neither");
     DFD_REQUIRE(!extra->pos || extra->frames_per_clip > 0, "dfd_gemm: QKV_EXPORT with pos needs frames_per_clip");
+  }
+  if (epilogue == DFD_EPI_RESIDUAL_POS) {
+    DFD_REQUIRE(extra && extra->tokens > 1, "dfd_gemm: RESIDUAL_POS needs extra.tokens (patches per frame + 1)");
+    DFD_REQUIRE(!extra->pos || extra->frames_per_clip > 0, "dfd_gemm: RESIDUAL_POS with pos needs frames_per_clip");
   }
   if (extra) {
     a.pos = extra->pos; a.cls = extra->cls; a.k_export = extra->k_export; a.v_export = extra->v_export;

@@ -290,6 +290,47 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
       }
     }
     return;
+  } else if constexpr (EPI == DFD_EPI_RESIDUAL_POS && sizeof(CT) == 2) {
+    // C(bf16) += acc + pos[frame % T]: park acc + pos as bf16?  No: the sum must be rounded once, so the
+    // f32 values are parked (two passes of 64 rows) and the read-modify-write happens at drain time.
+    const int nb = n0 + wc * 64;
+    const int rows_per_frame = a.tokens - 1;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(ep + row * 256 + (((j * 4 + fq) ^ (row & 15)) << 4)) = acc[half * 4 + i][j];
+      }
+      // drain: lane handles 8 consecutive columns (two parked 16-byte units) of one row: 8 rows x 128 B per store
+#pragma unroll 4
+      for (int rr = 0; rr < 8; ++rr) {
+        const int row = rr * 8 + (lane >> 3), c = lane & 7;
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(ep + row * 256 + (((2 * c) ^ (row & 15)) << 4));
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(ep + row * 256 + (((2 * c + 1) ^ (row & 15)) << 4));
+        const int64_t m = m0 + wr * 128 + half * 64 + row;
+        if (m < a.M) {
+          bf16x8* cp = reinterpret_cast<bf16x8*>(static_cast<bf16_t*>(a.C) + m * a.ldc + nb + c * 8);
+          const bf16x8 old = *cp;
+          f32x4 p0 = f32x4{0.f, 0.f, 0.f, 0.f}, p1 = p0;
+          if (a.pos) {
+            const float* pr = a.pos + ((m / rows_per_frame) % a.frames_per_clip) * a.N + nb + c * 8;
+            p0 = *reinterpret_cast<const f32x4*>(pr);
+            p1 = *reinterpret_cast<const f32x4*>(pr + 4);
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = (bf16_t)((float)old[e] + d0[e] + p0[e]);
+            o[4 + e] = (bf16_t)((float)old[4 + e] + d1[e] + p1[e]);
+          }
+          *cp = o;
+        }
+      }
+    }
+    return;
   } else if constexpr (EPI == DFD_EPI_BIAS_RESIDUAL) {
     const int nb = n0 + wc * 64;
     f32x4 b4[4];
@@ -438,6 +479,10 @@ int DFD_GEMM256_TRY(const GemmArgs& a, int c_dtype, int epi, hipStream_t st) {
       return c_dtype == DFD_BF16 ? launch256<bf16_t, DFD_EPI_QKV_EXPORT>(a, st) : launch256<float, DFD_EPI_QKV_EXPORT>(a, st);
     case DFD_EPI_BIAS_RESIDUAL:
       return c_dtype == DFD_F32 ? launch256<float, DFD_EPI_BIAS_RESIDUAL>(a, st) : 1;
+    case DFD_EPI_RESIDUAL_POS:
+      if (a.pos && (reinterpret_cast<uintptr_t>(a.pos) & 15) != 0) return 1;
+      if ((a.ldc % 8) != 0) return 1;
+      return c_dtype == DFD_BF16 ? launch256<bf16_t, DFD_EPI_RESIDUAL_POS>(a, st) : 1;
     case DFD_EPI_PATCH_EMBED:
       if ((reinterpret_cast<uintptr_t>(a.pos) & 15) != 0 || (reinterpret_cast<uintptr_t>(a.cls) & 15) != 0) return 1;
       return c_dtype == DFD_F32 ? launch256<float, DFD_EPI_PATCH_EMBED>(a, st) : 1;

@@ -20,6 +20,7 @@ from torch import nn
 
 from . import capi
 from .config import default_detector_config
+from .adapter import CompInvAdapter
 from .decoder import Decoder
 from .encoder import VisionTransformer
 from .weights import ARCHS, resolve_layer_indices
@@ -144,8 +145,19 @@ class Detector(nn.Module):
         self.decoder = Decoder(self, config, num_frames)
         if config.adapter.type == "none":
             self.adapter = None
+        elif config.adapter.type == "normal":
+            self.adapter = CompInvAdapter(config, self, num_frames=num_frames)
+            logging.info("Adapter operates without pretrained weights!!!")
+        elif config.adapter.type == "pretrain":
+            self.adapter = CompInvAdapter(config, self, num_frames=num_frames)
+            data = torch.load(config.adapter.path, map_location="cpu", weights_only=True)
+            data = {".".join(k.split(".")[1:]): v for k, v in data.items() if "adapter" in k}
+            self.adapter.load_state_dict(data)
+            if config.adapter.frozen:
+                self.adapter = disable_gradients(self.adapter)
+            logging.info(f"Adapter operates with pretrained weights:{config.adapter.path}")
         else:
-            raise NotImplementedError("CompInvAdapter is not built yet (SURVEY.md §8f rank 1)")
+            raise NotImplementedError()
         self.transform = ClipTransform(self.encoder.input_resolution)
         for key in ("patch_mask", "compression", "nerf_raw", "temporal"):
             if key in self.train_mode:
@@ -161,13 +173,29 @@ class Detector(nn.Module):
                                "at non-singleton dimension 1 (temporal positional embedding)")
         # the encoder is frozen and runs without autograd (reference models.py:440, :501); the decoder is
         # differentiable w.r.t. its own parameters
-        kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, self.decoder.temporal_pos())
+        pos = self.decoder.temporal_pos()
+        if self.adapter is None:
+            kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos)
+        else:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.adapter.parameters()):
+                raise NotImplementedError("training a non-frozen CompInvAdapter is not built yet: freeze it "
+                                          "(adapter.frozen = 1) or run under torch.no_grad()")
+            # raw K/V export, then adapter(kv) + pos in place (models.py:546-549, :326-329)
+            kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, None)
+            kv = self.adapter.apply_packed(kv[0], kv[1], t, pos)
         _, video_features, task_logits = self.decoder.run(kv, m)
         features = {}
         if with_video_features:
             features["video"] = video_features
         if with_adapt_features:
-            raise Exception("cannot return adaptive features without an adapter")
+            if self.adapter:
+                # as in the reference, what comes back has been flattened and pos-embedded by the decoder
+                # (models.py:329-334 mutate the dicts in place)
+                hh = self.encoder.heads
+                features["adapt"] = [{"k": kv[0][i].view(b, -1, hh, 64), "v": kv[1][i].view(b, -1, hh, 64)}
+                                     for i in range(len(self.layer_indices))]
+            else:
+                raise Exception("cannot return adaptive features without an adapter")
         return task_logits, features
 
     def forward(self, x, y, m, comp=None, speed=None, train=False, single_task=None, *args, **kargs):

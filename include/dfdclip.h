@@ -38,9 +38,13 @@ enum {
   DFD_EPI_BIAS_RESIDUAL,   /* C(f32) += acc + bias                — out_proj / c_proj + residual (clip/model.py:222-223) */
   DFD_EPI_PATCH_EMBED,     /* conv1-as-GEMM: scatter to token rows, + positional embedding, CLS row
                               (clip/model.py:277-291)                                              */
-  DFD_EPI_QKV_EXPORT       /* C = acc + bias AND export of the K / V column blocks, CLS row dropped,
+  DFD_EPI_QKV_EXPORT,      /* C = acc + bias AND export of the K / V column blocks, CLS row dropped,
                               temporal positional embedding added (clip/model.py:186-199,
                               models.py:505-509, :326-334)                                        */
+  DFD_EPI_RESIDUAL_POS     /* C(c_dtype) += acc + pos[(row / (tokens-1)) % T]: the adapter's second Linear,
+                              its residual and the decoder's positional add in one pass
+                              (models.py:935-937, :326-329); extra.pos may be NULL, extra.tokens-1 =
+                              rows (patches) per frame                                            */
 };
 
 typedef struct dfd_gemm_extra {
@@ -120,6 +124,12 @@ int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v, int kv_dt
 int dfd_head_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* proj,
                  float* video_feature, float* raw_logits, float* logits, int B, int D, int out_dim, float eps,
                  void* stream);
+
+/* CompInvAdapter middle stage (models.py:823-875): y = GELU_erf(LayerNorm(a)) on a [frames, patches, x]
+ * tensor in `dtype`.  joint != 0 ("nln"): statistics over the whole (patches, x) slab of a frame, affine
+ * weight/bias [patches, x]; joint == 0 ("ln"/"z0"): statistics per row of x, affine [x].  y may alias a. */
+int dfd_adapter_norm_gelu(const void* a, void* y, int dtype, const float* weight, const float* bias, int frames,
+                          int patches, int x, int joint, float eps, void* stream);
 
 /* ---- decoder backward (the encoder is frozen: reference models.py:440, :501; these are the
  *      gradients `accelerator.backward` produces in the reference train step, trainer.py:157-165) ---- */

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-3
 BF16_TOL = 5e-2
-SUPPORTED = ["tiny", "tiny_stride", "tiny_nopos", "tiny_augq", "small", "small14"]
+SUPPORTED = ["tiny", "tiny_stride", "tiny_nopos", "tiny_augq", "small", "small14", "tiny_adapter_nln", "tiny_adapter_ln"]
 
 
 def make_detector(case, precision):
@@ -110,3 +110,39 @@ def test_num_frames_mismatch_raises():
     det = make_detector(case, "fp32")
     with pytest.raises(RuntimeError), torch.no_grad():
         det.predict(case["x"][:, :3].cuda(), case["m"][:, :3].cuda())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("joint", [True, False])
+def test_adapter_stage_full_size(dtype, joint):
+    """CompInvAdapter on ViT-B/16-sized exports (196 patches, D=768, x=256: the tuned-GEMM shapes) vs the oracle."""
+    from dfd_clip_amd import capi
+    from dfd_clip_amd.adapter import CompInvAdapter
+    from dfd_clip_amd.config import ConfigNode
+    import types
+    B, T, P, D, x = 2, 3, 196, 768, 256
+    rng = np.random.default_rng(0)
+    f = lambda *s, sc=1.0: torch.from_numpy((rng.standard_normal(s) * sc).astype(np.float32))
+    struct = "768-x-768-nln" if joint else "768-x-768-ln"
+    cfg = ConfigNode({"dropout": 0.0, "adapter": {"struct": {"type": struct, "x": x}}})
+    det = types.SimpleNamespace(encoder=types.SimpleNamespace(width=D, input_resolution=224, patch_size=16), layer_indices=[0])
+    ad = CompInvAdapter(cfg, det, T)
+    w = {"adapter.l0_k.0.weight": f(x, D, sc=D ** -0.5), "adapter.l0_k.1.weight": 1 + 0.1 * f(*((P, x) if joint else (x,))),
+         "adapter.l0_k.1.bias": 0.1 * f(*((P, x) if joint else (x,))), "adapter.l0_k.4.weight": f(D, x, sc=x ** -0.5)}
+    for k_, v_ in list(w.items()):
+        w[k_.replace("l0_k", "l0_v")] = v_.flip(0).contiguous()
+    ad.load_state_dict({k_[len("adapter."):]: v_ for k_, v_ in w.items()})
+    ad = ad.cuda()
+    k, v, pos = f(B, T, P, 12, 64), f(B, T, P, 12, 64), f(T, 1, 12, 64)
+    if dtype == torch.bfloat16:
+        k, v = k.bfloat16().float(), v.bfloat16().float()
+        w = {k_: (v_.bfloat16().float() if k_.endswith(("0.weight", "4.weight")) else v_) for k_, v_ in w.items()}
+    want = ref_cpu.adapter_forward(w, [{"k": k, "v": v}], struct)[0]
+    kd = k.reshape(1, B * T * P, D).to(dtype).cuda()
+    vd = v.reshape(1, B * T * P, D).to(dtype).cuda()
+    ad.apply_packed(kd, vd, T, pos.reshape(T, D).cuda())
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+    for got, name in ((kd, "k"), (vd, "v")):
+        ref = (want[name] + pos).reshape(B * T * P, D)
+        err = (got[0].float().cpu() - ref).abs().max().item()
+        assert err <= tol, (name, err)

@@ -79,6 +79,18 @@ def test_full_size_schema_matches_reference_key_count():
 
 def test_unbuilt_variants_raise():
     from dfd_clip_amd.detector import Detector
-    cfg = make_config("tiny", adapter__type="normal", adapter__struct={"type": "768-x-768-nln", "x": 32})
+    cfg = make_config("tiny", adapter__type="normal", adapter__struct={"type": "768-bn", "x": 32})
     with pytest.raises(NotImplementedError):
         Detector(cfg, 4, None)
+    cfg = make_config("tiny", op_mode__global_prediction=1)
+    with pytest.raises(NotImplementedError):
+        Detector(cfg, 4, None)
+
+
+def test_adapter_state_dict_schema():
+    from dfd_clip_amd.detector import Detector
+    case = build_case("tiny_adapter_nln")
+    det = Detector(case["cfg"], case["T"], None, precision="fp32")
+    assert set(det.state_dict().keys()) == set(case["sd"].keys())
+    det.load_state_dict(case["sd"])
+    assert det.adapter.l0_k[1].weight.shape == (4, 32)
