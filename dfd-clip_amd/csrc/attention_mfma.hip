@@ -45,17 +45,30 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const bf16_t* __restr
   const bf16_t* base = qkv + (int64_t)frame * tokens * ld_qkv + head * HD;
 
   // ---- stage K (swizzled rows) and V (transposed); 8 lanes cover one 128-byte row ------------------
-  for (int c = tid; c < L::KEYS * 8; c += 256) {
+  // All of the workgroup's 2*NB global loads per thread are issued before the first LDS write: with
+  // only two workgroups per CU, serialising load -> write per iteration exposes NB HBM latencies.
+  constexpr int IT = L::KEYS * 8 / 256;  // = NB
+  bf16x8 kreg[IT], vreg[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int c = tid + it * 256;
     const int key = c >> 3, ch = c & 7;
-    bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    kreg[it] = z;
+    vreg[it] = z;
     if (key < tokens) {
       const bf16_t* src = base + (int64_t)key * ld_qkv + ch * 8;
-      kv = *reinterpret_cast<const bf16x8*>(src + D);
-      vv = *reinterpret_cast<const bf16x8*>(src + 2 * D);
+      kreg[it] = *reinterpret_cast<const bf16x8*>(src + D);
+      vreg[it] = *reinterpret_cast<const bf16x8*>(src + 2 * D);
     }
-    *reinterpret_cast<bf16x8*>(Ks + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = kv;
+  }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16_t*>(Vt + (ch * 8 + e) * L::VSTRIDE + key * 2) = vv[e];
+  for (int it = 0; it < IT; ++it) {
+    const int c = tid + it * 256;
+    const int key = c >> 3, ch = c & 7;
+    *reinterpret_cast<bf16x8*>(Ks + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = kreg[it];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16_t*>(Vt + (ch * 8 + e) * L::VSTRIDE + key * 2) = vreg[it][e];
   }
   __syncthreads();
 
