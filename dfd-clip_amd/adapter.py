@@ -10,8 +10,16 @@ Kernel sequence per (layer, tensor) on the packed export `[N*P, D]`:
     dfd_gemm(BIAS, bias = NULL)                    a1 = kv · W0ᵀ           [N*P, x]
     dfd_adapter_norm_gelu                          a2 = GELU(LN(a1))        "nln": stats over (P, x); "ln"/"z0": over x
     dfd_gemm(RESIDUAL_POS)                         kv += a2 · W4ᵀ + pos[frame % T]   (in place, one rounding)
-Eval-mode semantics (dropout = identity).  Forward only for now: training a non-frozen adapter
-needs the K/V gradients pushed through these three stages.
+Eval-mode semantics (dropout = identity).
+
+Training (`run`, with grad enabled and trainable parameters) goes through `_AdapterFn`: the forward is
+out of place and keeps a1; the backward takes dK/dV from the decoder's attention backward and runs
+    a2  = GELU(LN(a1))                      (recomputed)            dfd_adapter_norm_gelu
+    dW4 = dOutᵀ · a2                        [D, x]                  dfd_gemm_at_b   (split-K over B·T·P rows)
+    dA2 = dOut · W4                         [rows, x]               dfd_gemm
+    da1, dγ, dβ = LN/GELU backward                                  dfd_adapter_norm_gelu_bwd
+    dW0 = da1ᵀ · X                          [x, D]                  dfd_gemm_at_b
+The encoder output X needs no gradient (frozen encoder, reference models.py:440).
 """
 import torch
 from torch import nn
@@ -68,6 +76,78 @@ class CompInvAdapter(nn.Module):
             self._prep = (key, w)
         return self._prep[1]
 
+    def run(self, k_raw, v_raw, num_frames, temporal_pos):
+        """(k, v) = adapter(raw export) + pos.  In place without autograd; out of place through
+        `_AdapterFn` when gradients can flow to the adapter's parameters."""
+        names = [n for n, p in self.named_parameters()]
+        params = [p for n, p in self.named_parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _AdapterFn.apply(self, k_raw, v_raw, num_frames, temporal_pos, names, *params)
+        return self.apply_packed(k_raw, v_raw, num_frames, temporal_pos)
+
+    def _stage_weights(self, w, act):
+        out = {}
+        for i in range(self.n_layers):
+            for j in ("k", "v"):
+                pre = f"l{i}_{j}."
+                out[(i, j)] = (w[pre + "0.weight"].to(act).contiguous(), w[pre + "1.weight"].float().contiguous(),
+                               w[pre + "1.bias"].float().contiguous(), w[pre + "4.weight"].to(act).contiguous())
+        return out
+
+    def _forward_train(self, w, k_raw, v_raw, num_frames, temporal_pos):
+        act = k_raw.dtype
+        sw = self._stage_weights(w, act)
+        L, rows, D = k_raw.shape
+        P, x = self.patches, self.inner
+        frames = rows // P
+        joint = self.struct.endswith("nln")
+        k_out, v_out = torch.empty_like(k_raw), torch.empty_like(v_raw)
+        a1_all = torch.empty(L, 2, rows, x, device=k_raw.device, dtype=act)
+        a2 = torch.empty(rows, x, device=k_raw.device, dtype=act)
+        for i in range(L):
+            for jj, (j, src, dst) in enumerate((("k", k_raw, k_out), ("v", v_raw, v_out))):
+                w0, lw, lb, w4 = sw[(i, j)]
+                capi.gemm(src[i], w0, a1_all[i, jj], None, capi.EPI_BIAS)
+                capi.adapter_norm_gelu(a1_all[i, jj], a2, lw, lb, frames, P, x, joint)
+                capi.gemm(a2, w4, dst[i], None, capi.EPI_RESIDUAL_POS, pos=temporal_pos, tokens=P + 1, frames_per_clip=num_frames,
+                          residual=src[i])
+        return k_out, v_out, a1_all
+
+    def _backward_train(self, w, k_raw, v_raw, a1_all, dk, dv):
+        act = k_raw.dtype
+        sw = self._stage_weights(w, act)
+        L, rows, D = k_raw.shape
+        P, x = self.patches, self.inner
+        frames = rows // P
+        joint = self.struct.endswith("nln")
+        dev = k_raw.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        a2 = torch.empty(rows, x, device=dev, dtype=act)
+        da2 = torch.empty(rows, x, device=dev, dtype=act)
+        da1 = torch.empty(rows, x, device=dev, dtype=act)
+        nb = max(capi.gemm_at_b_workspace_bytes(rows, D, x, act), capi.gemm_at_b_workspace_bytes(rows, x, D, act))
+        ws_ab = torch.empty(nb // 4 + 64, **f32)
+        ws_ln = torch.empty(capi.adapter_norm_gelu_bwd_workspace_bytes(frames, P, x, joint) // 4 + 4, **f32)
+        grads = {}
+        for i in range(L):
+            for jj, (j, src, dout) in enumerate((("k", k_raw, dk), ("v", v_raw, dv))):
+                pre = f"l{i}_{j}."
+                w0, lw, lb, w4 = sw[(i, j)]
+                d_o = dout[i].to(act) if dout.dtype != act else dout[i]
+                a1 = a1_all[i, jj]
+                capi.adapter_norm_gelu(a1, a2, lw, lb, frames, P, x, joint)
+                dw4 = torch.empty(D, x, **f32)
+                capi.gemm_at_b(d_o, a2, dw4, ws_ab)
+                w4t = w[pre + "4.weight"].float().t().contiguous().to(act)  # [x, D]: dA2 = dOut @ W4 as A @ (W4^T)^T
+                capi.gemm(d_o, w4t, da2, None, capi.EPI_BIAS)
+                dlw, dlb = torch.empty_like(lw), torch.empty_like(lb)
+                capi.adapter_norm_gelu_bwd(a1, da2, da1, lw, lb, dlw, dlb, ws_ln, frames, P, x, joint)
+                dw0 = torch.empty(x, D, **f32)
+                capi.gemm_at_b(da1, src[i], dw0, ws_ab)
+                grads[pre + "0.weight"], grads[pre + "4.weight"] = dw0, dw4
+                grads[pre + "1.weight"], grads[pre + "1.bias"] = dlw, dlb
+        return grads
+
     @torch.no_grad()
     def apply_packed(self, k_all, v_all, num_frames, temporal_pos):
         """In place on the packed exports [L, N*P, D] (raw encoder K/V, no positional embedding yet):
@@ -88,3 +168,23 @@ class CompInvAdapter(nn.Module):
                 capi.adapter_norm_gelu(a1, a1, lw, lb, frames, P, x, joint)
                 capi.gemm(a1, w4, t[i], None, capi.EPI_RESIDUAL_POS, pos=temporal_pos, tokens=P + 1, frames_per_clip=num_frames)
         return k_all, v_all
+
+
+class _AdapterFn(torch.autograd.Function):
+    """autograd node around the adapter's HIP forward / backward.  Outputs (k, v) = adapter(raw) + pos."""
+
+    @staticmethod
+    def forward(ctx, adapter, k_raw, v_raw, num_frames, temporal_pos, names, *params):
+        w = {n: p.detach() for n, p in zip(names, params)}
+        k_out, v_out, a1_all = adapter._forward_train(w, k_raw, v_raw, num_frames, temporal_pos)
+        ctx.adapter, ctx.w, ctx.names = adapter, w, names
+        ctx.saved = (k_raw, v_raw, a1_all)
+        ctx.req = [p.requires_grad for p in params]
+        return k_out, v_out
+
+    @staticmethod
+    def backward(ctx, dk, dv):
+        k_raw, v_raw, a1_all = ctx.saved
+        grads = ctx.adapter._backward_train(ctx.w, k_raw, v_raw, a1_all, dk.contiguous(), dv.contiguous())
+        out = [grads.get(nm) if rq else None for nm, rq in zip(ctx.names, ctx.req)]
+        return (None, None, None, None, None, None, *out)

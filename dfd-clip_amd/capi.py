@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT, EPI_RESIDUAL_POS = range(6)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -26,7 +26,7 @@ class DfdError(RuntimeError):
 
 class GemmExtra(Structure):
     _fields_ = [("pos", c_void_p), ("cls", c_void_p), ("k_export", c_void_p), ("v_export", c_void_p),
-                ("tokens", c_int32), ("frames_per_clip", c_int32)]
+                ("tokens", c_int32), ("frames_per_clip", c_int32), ("residual", c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/dfdclip.h one to one
@@ -38,6 +38,8 @@ SIGNATURES = {
     "dfd_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dfd_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int,
                          POINTER(GemmExtra), c_int64, c_int, c_int, c_void_p]),
+    "dfd_gemm_at_b_workspace": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "dfd_gemm_at_b": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "dfd_adapter_norm_gelu": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dfd_attention_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dfd_linear_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
@@ -49,7 +51,10 @@ SIGNATURES = {
                                      c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dfd_decoder_attn_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dfd_decoder_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dfd_adapter_norm_gelu_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dfd_adapter_norm_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dfd_linear_rows_bwd_weight": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dfd_transpose_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dfd_layernorm_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
@@ -150,14 +155,16 @@ def profile_gemm_collect():
 
 
 def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_export=None, v_export=None, tokens=0,
-         frames_per_clip=0):
+         frames_per_clip=0, residual=None):
     """c = epilogue(a[M,K] @ w[N,K]^T).  `m` limits the rows used (buffers may be over-allocated)."""
-    _dev(a, w, c, bias, pos, cls, k_export, v_export)
+    _dev(a, w, c, bias, pos, cls, k_export, v_export, residual)
     assert a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1 and c.stride(1) == 1
     M = a.shape[0] if m is None else m
     N, K = w.shape
     assert a.shape[1] == K
-    extra = GemmExtra(_ptr(pos).value, _ptr(cls).value, _ptr(k_export).value, _ptr(v_export).value, tokens, frames_per_clip)
+    assert residual is None or (residual.dtype == c.dtype and residual.stride(0) == c.stride(0))
+    extra = GemmExtra(_ptr(pos).value, _ptr(cls).value, _ptr(k_export).value, _ptr(v_export).value, tokens, frames_per_clip,
+                      _ptr(residual).value)
     timed = _profile["epilogue"] == epilogue
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -170,6 +177,23 @@ def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_ex
     return c
 
 
+def gemm_at_b_workspace_bytes(R, Ma, Nb, dtype):
+    return load_library().dfd_gemm_at_b_workspace(R, Ma, Nb, _DTYPE[dtype])
+
+
+def gemm_at_b(a, b, c, workspace):
+    """c[Ma, Nb] (f32) = a[R, Ma]^T @ b[R, Nb]."""
+    _dev(a, b, c, workspace)
+    assert a.dtype == b.dtype and a.stride(1) == 1 and b.stride(1) == 1 and c.is_contiguous() and c.dtype == torch.float32
+    R, Ma = a.shape
+    Nb = b.shape[1]
+    assert b.shape[0] == R and tuple(c.shape) == (Ma, Nb)
+    assert workspace.numel() * workspace.element_size() >= gemm_at_b_workspace_bytes(R, Ma, Nb, a.dtype)
+    _check(load_library().dfd_gemm_at_b(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _DTYPE[a.dtype], _ptr(c), R, Ma, Nb,
+                                        _ptr(workspace), _stream()), "dfd_gemm_at_b")
+    return c
+
+
 def adapter_norm_gelu(a, y, weight, bias, frames, patches, x, joint, eps=1e-5):
     """y = GELU(LayerNorm(a)) on [frames, patches, x]; joint: statistics over (patches, x), else per row."""
     _dev(a, y, weight, bias)
@@ -177,6 +201,19 @@ def adapter_norm_gelu(a, y, weight, bias, frames, patches, x, joint, eps=1e-5):
     _check(load_library().dfd_adapter_norm_gelu(_ptr(a), _ptr(y), _DTYPE[a.dtype], _ptr(weight), _ptr(bias), frames, patches, x,
                                                 int(joint), eps, _stream()), "dfd_adapter_norm_gelu")
     return y
+
+
+def adapter_norm_gelu_bwd_workspace_bytes(frames, patches, x, joint):
+    return load_library().dfd_adapter_norm_gelu_bwd_workspace(frames, patches, x, int(joint))
+
+
+def adapter_norm_gelu_bwd(a, dy, da, weight, bias, dweight, dbias, workspace, frames, patches, x, joint, eps=1e-5):
+    _dev(a, dy, da, weight, bias, dweight, dbias, workspace)
+    assert a.dtype == dy.dtype == da.dtype and a.is_contiguous() and dy.is_contiguous() and da.is_contiguous()
+    _check(load_library().dfd_adapter_norm_gelu_bwd(_ptr(a), _ptr(dy), _ptr(da), _DTYPE[a.dtype], _ptr(weight), _ptr(bias),
+                                                    _ptr(dweight), _ptr(dbias), _ptr(workspace), frames, patches, x, int(joint),
+                                                    eps, _stream()), "dfd_adapter_norm_gelu_bwd")
+    return da
 
 
 def attention_fwd(qkv, out, n_frames, tokens, heads, head_dim=64):
@@ -251,7 +288,8 @@ def decoder_attn_bwd(q, k, v, frame_mask, dmix, mix_softmax, stats, dq, dpos, wo
     assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and dmix.is_contiguous() and mix_softmax.is_contiguous()
     _check(load_library().dfd_decoder_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _DTYPE[k.dtype], _ptr(frame_mask), _ptr(dmix),
                                                _ptr(mix_softmax), _ptr(stats), _ptr(dq), _ptr(dpos), _ptr(dk), _ptr(dv),
-                                               _ptr(workspace), B, T, patches, heads, d, _stream()), "dfd_decoder_attn_bwd")
+                                               _DTYPE[dk.dtype] if dk is not None else F32, _ptr(workspace), B, T, patches,
+                                               heads, d, _stream()), "dfd_decoder_attn_bwd")
     return dq
 
 

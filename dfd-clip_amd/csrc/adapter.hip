@@ -56,7 +56,138 @@ __global__ __launch_bounds__(256) void adapter_ln_kernel(const T* __restrict__ a
   for (int i = lane; i < x; i += 64) yp[i] = from_f32<T>(gelu_erf((ld(ap + i) - mean) * rstd * w[i] + b[i]));
 }
 
+__device__ __forceinline__ float gelu_erf_grad(float z) {
+  return 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+}
+
+// ---- backward, pass 1: one workgroup per normalisation group (frame slab for "nln", row for "ln") -------
+// da = rstd * (g - mean(g) - nhat * mean(g * nhat)),  g = dy * gelu'(nhat*w + b) * w;  saves (mean, rstd)
+template <typename T>
+__global__ __launch_bounds__(1024) void adapter_bwd_group_kernel(const T* __restrict__ a, const T* __restrict__ dy,
+                                                                 T* __restrict__ da, const float* __restrict__ w,
+                                                                 const float* __restrict__ b, float* __restrict__ stats,
+                                                                 int group, int affine_period, float eps) {
+  __shared__ float sc[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const T* ap = a + (int64_t)blockIdx.x * group;
+  const T* dp = dy + (int64_t)blockIdx.x * group;
+  T* op = da + (int64_t)blockIdx.x * group;
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sc[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += sc[i];
+    return t;
+  };
+  float s = 0.f;
+  for (int i = tid; i < group; i += blockDim.x) s += ld(ap + i);
+  const float mean = block_sum(s) / (float)group;
+  float q = 0.f;
+  for (int i = tid; i < group; i += blockDim.x) { const float d = ld(ap + i) - mean; q += d * d; }
+  const float rstd = rsqrtf(block_sum(q) / (float)group + eps);
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = tid; i < group; i += blockDim.x) {
+    const int e = i % affine_period;
+    const float nh = (ld(ap + i) - mean) * rstd;
+    const float g = ld(dp + i) * gelu_erf_grad(nh * w[e] + b[e]) * w[e];
+    s1 += g;
+    s2 += g * nh;
+  }
+  const float m1 = block_sum(s1) / (float)group, m2 = block_sum(s2) / (float)group;
+  for (int i = tid; i < group; i += blockDim.x) {
+    const int e = i % affine_period;
+    const float nh = (ld(ap + i) - mean) * rstd;
+    const float g = ld(dp + i) * gelu_erf_grad(nh * w[e] + b[e]) * w[e];
+    op[i] = from_f32<T>(rstd * (g - m1 - nh * m2));
+  }
+  if (tid == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
+}
+
+// ---- backward, pass 2: affine gradients.  Thread per affine element e, block-row per chunk of groups;
+// partial sums go to slab blockIdx.y and are added in fixed order by adapter_bwd_affine_reduce_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void adapter_bwd_affine_kernel(const T* __restrict__ a, const T* __restrict__ dy,
+                                                                 const float* __restrict__ w, const float* __restrict__ b,
+                                                                 const float* __restrict__ stats, float* __restrict__ part,
+                                                                 int64_t groups, int group, int affine, int groups_per_slab) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= affine) return;
+  const int reps = group / affine;  // rows of an affine period inside one group (1 for nln, 1 for ln)
+  const int64_t g0 = (int64_t)blockIdx.y * groups_per_slab;
+  const int64_t g1 = g0 + groups_per_slab < groups ? g0 + groups_per_slab : groups;
+  const float we = w[e], be = b[e];
+  float dw = 0.f, db = 0.f;
+  for (int64_t gi = g0; gi < g1; ++gi) {
+    const float mean = stats[2 * gi], rstd = stats[2 * gi + 1];
+    for (int r = 0; r < reps; ++r) {
+      const int64_t idx = gi * group + (int64_t)r * affine + e;
+      const float nh = (ld(a + idx) - mean) * rstd;
+      const float dz = ld(dy + idx) * gelu_erf_grad(nh * we + be);
+      dw = fmaf(dz, nh, dw);
+      db += dz;
+    }
+  }
+  part[((int64_t)blockIdx.y * 2) * affine + e] = dw;
+  part[((int64_t)blockIdx.y * 2 + 1) * affine + e] = db;
+}
+
+__global__ void adapter_bwd_affine_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                                 int affine, int slabs) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= affine) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int z = 0; z < slabs; ++z) { s0 += part[((int64_t)z * 2) * affine + e]; s1 += part[((int64_t)z * 2 + 1) * affine + e]; }
+  dw[e] = s0;
+  db[e] = s1;
+}
+
+int affine_slabs(int64_t groups, int affine) {
+  // enough (element, chunk) threads to cover the chip; at most 512 slabs
+  int64_t want = (262144 + affine - 1) / affine;
+  if (want > groups) want = groups;
+  if (want > 512) want = 512;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
 }  // namespace
+
+extern "C" size_t dfd_adapter_norm_gelu_bwd_workspace(int frames, int patches, int x, int joint) {
+  if (frames <= 0 || patches <= 0 || x <= 0) return 0;
+  const int64_t groups = joint ? frames : (int64_t)frames * patches;
+  const int affine = joint ? patches * x : x;
+  return (size_t)groups * 2 * sizeof(float) + (size_t)affine_slabs(groups, affine) * 2 * affine * sizeof(float);
+}
+
+extern "C" int dfd_adapter_norm_gelu_bwd(const void* a, const void* dy, void* da, int dtype, const float* weight,
+                                         const float* bias, float* dweight, float* dbias, void* workspace, int frames,
+                                         int patches, int x, int joint, float eps, void* stream) {
+  DFD_REQUIRE(a && dy && da && weight && bias && dweight && dbias && workspace, "dfd_adapter_norm_gelu_bwd: null pointer");
+  DFD_REQUIRE(frames > 0 && patches > 0 && x > 0, "dfd_adapter_norm_gelu_bwd: bad shape");
+  DFD_REQUIRE(da != dy && da != a, "dfd_adapter_norm_gelu_bwd: da must not alias dy or a (both are re-read by the affine pass)");
+  DFD_REQUIRE(dtype == DFD_F32 || dtype == DFD_BF16, "dfd_adapter_norm_gelu_bwd: dtype=%d", dtype);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t groups = joint ? frames : (int64_t)frames * patches;
+  const int group = joint ? patches * x : x;
+  const int affine = group;
+  float* stats = static_cast<float*>(workspace);
+  float* part = stats + groups * 2;
+  const int slabs = affine_slabs(groups, affine);
+  const int gps = (int)((groups + slabs - 1) / slabs);
+  const int threads = joint ? 1024 : 64;
+#define ADP_LAUNCH(T)                                                                                                     \
+  hipLaunchKernelGGL((adapter_bwd_group_kernel<T>), dim3((unsigned)groups), dim3(threads), 0, st, static_cast<const T*>(a),  \
+                     static_cast<const T*>(dy), static_cast<T*>(da), weight, bias, stats, group, affine, eps);             \
+  hipLaunchKernelGGL((adapter_bwd_affine_kernel<T>), dim3((affine + 255) / 256, slabs), dim3(256), 0, st,                    \
+                     static_cast<const T*>(a), static_cast<const T*>(dy), weight, bias, stats, part, groups, group, affine, gps);
+  if (dtype == DFD_F32) { ADP_LAUNCH(float) } else { ADP_LAUNCH(bf16_t) }
+#undef ADP_LAUNCH
+  hipLaunchKernelGGL(adapter_bwd_affine_reduce_kernel, dim3((affine + 255) / 256), dim3(256), 0, st, part, dweight, dbias, affine, slabs);
+  DFD_CHECK_LAUNCH("dfd_adapter_norm_gelu_bwd");
+  return DFD_OK;
+}
 
 extern "C" int dfd_adapter_norm_gelu(const void* a, void* y, int dtype, const float* weight, const float* bias, int frames,
                                      int patches, int x, int joint, float eps, void* stream) {

@@ -41,14 +41,14 @@ __device__ __forceinline__ float group8_sum(float v) {
 __device__ __forceinline__ float sgn(float x) { return (float)(x > 0.f) - (float)(x < 0.f); }
 
 // grid (T, B).  part layout per (b, t): [heads][128] dq (softmax query | CoDA query), then [heads*64] dpos.
-template <typename T>
+template <typename T, typename G>
 __global__ __launch_bounds__(1024) void decoder_attn_bwd_kernel(const float* __restrict__ q, const T* __restrict__ k,
                                                                 const T* __restrict__ v,
                                                                 const uint8_t* __restrict__ frame_mask,
                                                                 const float* __restrict__ dmix,
                                                                 const float* __restrict__ mix_s,
                                                                 const float* __restrict__ stats, float* __restrict__ part,
-                                                                float* __restrict__ dk_out, float* __restrict__ dv_out,
+                                                                G* __restrict__ dk_out, G* __restrict__ dv_out,
                                                                 int T_frames, int patches, int heads, int R) {
   extern __shared__ float red[];  // [R][tpr][24]
   const int tpr = heads * 8;
@@ -126,18 +126,18 @@ __global__ __launch_bounds__(1024) void decoder_attn_bwd_kernel(const float* __r
         dkk[e] = (ds * qs[e] + dt * qc[e]) * 0.125f - sg;
       }
       if (dk_out != nullptr) {
-        float* ko = dk_out + ((int64_t)b * S + s0 + j) * D + hd * HD + sub * 8;
-        float* vo = dv_out + ((int64_t)b * S + s0 + j) * D + hd * HD + sub * 8;
+        G* ko = dk_out + ((int64_t)b * S + s0 + j) * D + hd * HD + sub * 8;
+        G* vo = dv_out + ((int64_t)b * S + s0 + j) * D + hd * HD + sub * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ko[e] = dkk[e]; vo[e] = w * dm[e]; }
+        for (int e = 0; e < 8; ++e) { ko[e] = from_f32<G>(dkk[e]); vo[e] = from_f32<G>(w * dm[e]); }
       }
     }
   } else if (dk_out != nullptr) {
     for (int j = rs; j < patches; j += R) {
-      float* ko = dk_out + ((int64_t)b * S + t * patches + j) * D + hd * HD + sub * 8;
-      float* vo = dv_out + ((int64_t)b * S + t * patches + j) * D + hd * HD + sub * 8;
+      G* ko = dk_out + ((int64_t)b * S + t * patches + j) * D + hd * HD + sub * 8;
+      G* vo = dv_out + ((int64_t)b * S + t * patches + j) * D + hd * HD + sub * 8;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { ko[e] = 0.f; vo[e] = 0.f; }
+      for (int e = 0; e < 8; ++e) { ko[e] = from_f32<G>(0.f); vo[e] = from_f32<G>(0.f); }
     }
   }
   // Σ_j (dK_j + dV_j) for this thread's 8 channels
@@ -346,13 +346,14 @@ extern "C" size_t dfd_decoder_attn_bwd_workspace(int B, int T, int heads, int d)
 
 extern "C" int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v, int kv_dtype, const uint8_t* frame_mask,
                                     const float* dmix, const float* mix_softmax, const float* stats, float* dq, float* dpos,
-                                    float* dk, float* dv, void* workspace, int B, int T, int patches, int heads, int d,
-                                    void* stream) {
+                                    void* dk, void* dv, int dkv_dtype, void* workspace, int B, int T, int patches, int heads,
+                                    int d, void* stream) {
   DFD_REQUIRE(q && k && v && frame_mask && dmix && mix_softmax && stats && dq && workspace, "dfd_decoder_attn_bwd: null pointer");
   DFD_REQUIRE(d == HD, "dfd_decoder_attn_bwd: head dim %d, only 64 is supported", d);
   DFD_REQUIRE(B >= 0 && T > 0 && patches > 0 && heads > 0 && heads * HD <= 1024, "dfd_decoder_attn_bwd: bad shape");
   DFD_REQUIRE(kv_dtype == DFD_F32 || kv_dtype == DFD_BF16, "dfd_decoder_attn_bwd: kv_dtype=%d", kv_dtype);
   DFD_REQUIRE(!dk == !dv, "dfd_decoder_attn_bwd: dk and dv must both be given or both be NULL");
+  DFD_REQUIRE(!dk || dkv_dtype == DFD_F32 || dkv_dtype == DFD_BF16, "dfd_decoder_attn_bwd: dkv_dtype=%d", dkv_dtype);
   DFD_REQUIRE(dfd_aligned16(k) && dfd_aligned16(v), "dfd_decoder_attn_bwd: k and v must be 16-byte aligned");
   if (B == 0) return DFD_OK;
   const int R = rows_per_block(heads);
@@ -361,16 +362,20 @@ extern "C" int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v
   const int D = heads * HD;
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* part = static_cast<float*>(workspace);
-  if (lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decoder_attn_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decoder_attn_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
-  if (kv_dtype == DFD_F32)
-    hipLaunchKernelGGL((decoder_attn_bwd_kernel<float>), dim3(T, B), dim3(threads), lds, st, q, static_cast<const float*>(k),
-                       static_cast<const float*>(v), frame_mask, dmix, mix_softmax, stats, part, dk, dv, T, patches, heads, R);
-  else
-    hipLaunchKernelGGL((decoder_attn_bwd_kernel<bf16_t>), dim3(T, B), dim3(threads), lds, st, q, static_cast<const bf16_t*>(k),
-                       static_cast<const bf16_t*>(v), frame_mask, dmix, mix_softmax, stats, part, dk, dv, T, patches, heads, R);
+  const dim3 grid(T, B), block(threads);
+#define BWD_LAUNCH(KT, GT)                                                                                                  \
+  do {                                                                                                                      \
+    if (lds > 64 * 1024)                                                                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decoder_attn_bwd_kernel<KT, GT>),                             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
+    hipLaunchKernelGGL((decoder_attn_bwd_kernel<KT, GT>), grid, block, lds, st, q, static_cast<const KT*>(k),                  \
+                       static_cast<const KT*>(v), frame_mask, dmix, mix_softmax, stats, part, static_cast<GT*>(dk),           \
+                       static_cast<GT*>(dv), T, patches, heads, R);                                                         \
+  } while (0)
+  const bool gb = dk && dkv_dtype == DFD_BF16;
+  if (kv_dtype == DFD_F32) { if (gb) BWD_LAUNCH(float, bf16_t); else BWD_LAUNCH(float, float); }
+  else { if (gb) BWD_LAUNCH(bf16_t, bf16_t); else BWD_LAUNCH(bf16_t, float); }
+#undef BWD_LAUNCH
   DFD_CHECK_LAUNCH("dfd_decoder_attn_bwd");
   const int total = B * 2 * D + (dpos ? T * D : 0);
   hipLaunchKernelGGL(decoder_attn_bwd_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, dq, dpos, B, T, D);

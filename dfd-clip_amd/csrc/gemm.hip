@@ -19,6 +19,7 @@ constexpr int BM = 128, BN = 128;
 constexpr int ROW_BYTES = 64;   // K bytes per row per step
 constexpr int ROW_STRIDE = 80;  // padded LDS row
 constexpr int TILE_BYTES = BM * ROW_STRIDE;
+constexpr int EPI_SPLITK_SLAB = 100;  // internal: raw f32 accumulators to slab blockIdx.z of C
 
 template <typename CT> __device__ __forceinline__ void store_c(void* C, int64_t off, float v) {
   static_cast<CT*>(C)[off] = from_f32<CT>(v);
@@ -45,7 +46,8 @@ __device__ __forceinline__ void epilogue_elem(const GemmArgs& a, int64_t m, int 
     const int64_t frame = m / (a.tokens - 1);
     const float p = a.pos ? a.pos[(frame % a.frames_per_clip) * a.N + n] : 0.f;
     CT* c = static_cast<CT*>(a.C) + m * a.ldc + n;
-    *c = from_f32<CT>(to_f32(*c) + acc + p);
+    const CT* rsd = a.residual ? static_cast<const CT*>(a.residual) + m * a.ldc + n : c;
+    *c = from_f32<CT>(to_f32(*rsd) + acc + p);
   } else if constexpr (EPI == DFD_EPI_QKV_EXPORT) {
     const float v = acc + (a.bias ? a.bias[n] : 0.f);
     store_c<CT>(a.C, m * a.ldc + n, v);
@@ -73,7 +75,11 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmArgs a) {
   const int64_t m0 = (int64_t)blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
   constexpr int KSTEP = ROW_BYTES / (int)sizeof(T);  // elements of K per step
-  const int nk = a.K / KSTEP;
+  // split-K (gridDim.z > 1): slice z covers K steps [z*per, (z+1)*per) and writes its own f32 slab of C
+  const int nk_all = a.K / KSTEP;
+  const int per = (nk_all + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int kt0 = (int)blockIdx.z * per;
+  const int nk = min(per, nk_all - kt0) > 0 ? min(per, nk_all - kt0) : 0;
 
   // staging assignment: 512 16-byte chunks per matrix tile, 2 per thread
   const unsigned char* Ab = static_cast<const unsigned char*>(a.A);
@@ -96,8 +102,8 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmArgs a) {
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      ra[i] = va[i] ? *reinterpret_cast<const uint4*>(pa[i] + (int64_t)kt * ROW_BYTES) : uint4{0, 0, 0, 0};
-      rb[i] = vb[i] ? *reinterpret_cast<const uint4*>(pb[i] + (int64_t)kt * ROW_BYTES) : uint4{0, 0, 0, 0};
+      ra[i] = va[i] ? *reinterpret_cast<const uint4*>(pa[i] + (int64_t)(kt0 + kt) * ROW_BYTES) : uint4{0, 0, 0, 0};
+      rb[i] = vb[i] ? *reinterpret_cast<const uint4*>(pb[i] + (int64_t)(kt0 + kt) * ROW_BYTES) : uint4{0, 0, 0, 0};
     }
   };
   auto store_tile = [&](int buf) {
@@ -116,8 +122,10 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  load_tile(0);
-  store_tile(0);
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
@@ -169,7 +177,11 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmArgs a) {
       for (int e = 0; e < 16; ++e) {
         const int64_t m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         const int n = n0 + wn * 64 + j * 32 + r;
-        epilogue_elem<CT, EPI>(a, m, n, acc[i][j][e]);
+        if constexpr (EPI == EPI_SPLITK_SLAB) {
+          if (m < a.M && n < a.N) static_cast<float*>(a.C)[((int64_t)blockIdx.z * a.M + m) * a.ldc + n] = acc[i][j][e];
+        } else {
+          epilogue_elem<CT, EPI>(a, m, n, acc[i][j][e]);
+        }
       }
 }
 
@@ -201,6 +213,62 @@ int launch_gemm128(const GemmArgs& a, int epi, hipStream_t st) {
   }
 #undef EPI_CASE
   DFD_CHECK_LAUNCH("dfd_gemm");
+  return DFD_OK;
+}
+
+// ---- C = Aᵀ·B for tall operands (weight gradients): transposes + split-K on the kernel above ----------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict__ src, int64_t lds_, T* __restrict__ dst, int64_t R,
+                                                            int C, int64_t Rp) {
+  __shared__ T tile[32][33];
+  const int c0 = blockIdx.x * 32;
+  const int64_t r0 = (int64_t)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) tile[i][tx] = (r0 + i < R && c0 + tx < C) ? src[(r0 + i) * lds_ + c0 + tx] : from_f32<T>(0.f);
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < C && r0 + tx < Rp) dst[(int64_t)(c0 + i) * Rp + r0 + tx] = tile[tx][i];
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int splits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * n + i];
+  out[i] = s;
+}
+
+void at_b_plan(int64_t R, int Ma, int Nb, int64_t* Rp, int* splits) {
+  const int tiles = ((Ma + BM - 1) / BM) * ((Nb + BN - 1) / BN);
+  int sp = (1024 + tiles - 1) / tiles;                       // ~4 workgroups per CU in flight
+  const int64_t steps = (R + 31) / 32;
+  if (sp > steps / 8) sp = (int)(steps / 8 > 0 ? steps / 8 : 1);  // at least 8 K steps per slice
+  if (sp > 512) sp = 512;
+  *splits = sp;
+  *Rp = (R + 31) / 32 * 32;
+}
+
+template <typename T>
+int launch_at_b(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t R, int Ma, int Nb, void* workspace,
+                hipStream_t st) {
+  int64_t Rp;
+  int splits;
+  at_b_plan(R, Ma, Nb, &Rp, &splits);
+  T* At = static_cast<T*>(workspace);
+  T* Bt = At + (int64_t)Ma * Rp;
+  size_t off = (size_t)(Ma + Nb) * Rp * sizeof(T);
+  off = (off + 255) / 256 * 256;
+  float* slabs = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + off);
+  const dim3 tb(256);
+  hipLaunchKernelGGL((transpose_pad_kernel<T>), dim3((Ma + 31) / 32, (unsigned)(Rp / 32)), tb, 0, st, static_cast<const T*>(A), lda, At, R, Ma, Rp);
+  hipLaunchKernelGGL((transpose_pad_kernel<T>), dim3((Nb + 31) / 32, (unsigned)(Rp / 32)), tb, 0, st, static_cast<const T*>(B), ldb, Bt, R, Nb, Rp);
+  GemmArgs a{};
+  a.A = At; a.W = Bt; a.C = slabs; a.lda = Rp; a.ldw = Rp; a.ldc = Nb; a.M = Ma; a.N = Nb; a.K = (int)Rp;
+  const dim3 grid((Nb + BN - 1) / BN, (Ma + BM - 1) / BM, splits);
+  hipLaunchKernelGGL((gemm128_kernel<T, float, EPI_SPLITK_SLAB>), grid, tb, 0, st, a);
+  const int64_t n = (int64_t)Ma * Nb;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), tb, 0, st, slabs, C, n, splits);
+  DFD_CHECK_LAUNCH("dfd_gemm_at_b");
   return DFD_OK;
 }
 
@@ -240,6 +308,7 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
   }
   if (extra) {
     a.pos = extra->pos; a.cls = extra->cls; a.k_export = extra->k_export; a.v_export = extra->v_export;
+    a.residual = epilogue == DFD_EPI_RESIDUAL_POS ? extra->residual : nullptr;
     a.tokens = extra->tokens; a.frames_per_clip = extra->frames_per_clip > 0 ? extra->frames_per_clip : 1;
   }
   if (M == 0) return DFD_OK;
@@ -251,4 +320,27 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
   if (ab_dtype == DFD_F32) return launch_gemm128<float, float>(a, epilogue, st);
   if (c_dtype == DFD_BF16) return launch_gemm128<bf16_t, bf16_t>(a, epilogue, st);
   return launch_gemm128<bf16_t, float>(a, epilogue, st);
+}
+
+extern "C" size_t dfd_gemm_at_b_workspace(int64_t R, int Ma, int Nb, int dtype) {
+  if (R <= 0 || Ma <= 0 || Nb <= 0) return 0;
+  int64_t Rp;
+  int splits;
+  at_b_plan(R, Ma, Nb, &Rp, &splits);
+  const size_t esz = dtype == DFD_F32 ? 4 : 2;
+  size_t bytes = (size_t)(Ma + Nb) * Rp * esz;
+  bytes = (bytes + 255) / 256 * 256;
+  return bytes + (size_t)splits * Ma * Nb * sizeof(float) + 256;
+}
+
+extern "C" int dfd_gemm_at_b(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C, int64_t R, int Ma,
+                             int Nb, void* workspace, void* stream) {
+  DFD_REQUIRE(A && B && C && workspace, "dfd_gemm_at_b: null pointer");
+  DFD_REQUIRE(R > 0 && Ma > 0 && Nb > 0 && lda >= Ma && ldb >= Nb, "dfd_gemm_at_b: bad shape");
+  DFD_REQUIRE(R < (int64_t)1 << 31, "dfd_gemm_at_b: R too large");
+  DFD_REQUIRE(dtype == DFD_F32 || dtype == DFD_BF16, "dfd_gemm_at_b: dtype=%d", dtype);
+  DFD_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "dfd_gemm_at_b: workspace must be 256-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == DFD_F32) return launch_at_b<float>(A, lda, B, ldb, C, R, Ma, Nb, workspace, st);
+  return launch_at_b<bf16_t>(A, lda, B, ldb, C, R, Ma, Nb, workspace, st);
 }

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
         const int64_t m = m0 + wr * 128 + half * 64 + row;
         if (m < a.M) {
           bf16x8* cp = reinterpret_cast<bf16x8*>(static_cast<bf16_t*>(a.C) + m * a.ldc + nb + c * 8);
-          const bf16x8 old = *cp;
+          const bf16x8 old = a.residual ? *reinterpret_cast<const bf16x8*>(static_cast<const bf16_t*>(a.residual) + m * a.ldc + nb + c * 8) : *cp;
           f32x4 p0 = f32x4{0.f, 0.f, 0.f, 0.f}, p1 = p0;
           if (a.pos) {
             const float* pr = a.pos + ((m / rows_per_frame) % a.frames_per_clip) * a.N + nb + c * 8;
@@ -481,7 +481,7 @@ int DFD_GEMM256_TRY(const GemmArgs& a, int c_dtype, int epi, hipStream_t st) {
       return c_dtype == DFD_F32 ? launch256<float, DFD_EPI_BIAS_RESIDUAL>(a, st) : 1;
     case DFD_EPI_RESIDUAL_POS:
       if (a.pos && (reinterpret_cast<uintptr_t>(a.pos) & 15) != 0) return 1;
-      if ((a.ldc % 8) != 0) return 1;
+      if ((a.ldc % 8) != 0 || (reinterpret_cast<uintptr_t>(a.residual) & 15) != 0) return 1;
       return c_dtype == DFD_BF16 ? launch256<bf16_t, DFD_EPI_RESIDUAL_POS>(a, st) : 1;
     case DFD_EPI_PATCH_EMBED:
       if ((reinterpret_cast<uintptr_t>(a.pos) & 15) != 0 || (reinterpret_cast<uintptr_t>(a.cls) & 15) != 0) return 1;

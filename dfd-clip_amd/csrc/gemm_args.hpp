@@ -11,6 +11,7 @@ struct GemmArgs {
   const float* cls;
   void* k_export;
   void* v_export;
+  const void* residual;  // RESIDUAL_POS: source of the residual (NULL = C itself, in place)
   int64_t lda, ldw, ldc, M;
   int N, K, tokens, frames_per_clip;
 };

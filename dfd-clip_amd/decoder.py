@@ -156,7 +156,7 @@ class Decoder(nn.Module):
         k_all, v_all, mask, B, T, P = self._unpack(kvs, m)
         names = [n for n, p in self.named_parameters()]
         params = [p for n, p in self.named_parameters()]
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in params) or k_all.requires_grad):
             out = _DecoderFn.apply(self, k_all, v_all, mask, (B, T, P), names, *params)
             n = len(self.out_dims)
             return list(out[1:1 + n]), out[0], list(out[1 + n:1 + 2 * n])
@@ -227,9 +227,10 @@ class Decoder(nn.Module):
         return raws, feat, outs, saved
 
     # ---- backward on HIP kernels -------------------------------------------------------------
-    def _backward_kernels(self, w, saved, k_all, v_all, mask, B, T, P, d_feat, d_raws, d_logits):
+    def _backward_kernels(self, w, saved, k_all, v_all, mask, B, T, P, d_feat, d_raws, d_logits, want_dkv=False):
         """Gradients of every decoder parameter (dict name -> tensor), given dL/d(video_feature),
-        dL/d(raw logits) and dL/d(normalised logits) (any may be None)."""
+        dL/d(raw logits) and dL/d(normalised logits) (any may be None).  With `want_dkv` the full
+        key/value gradients [L, B*S, D] (in the K/V dtype) come back under "__dk" / "__dv"."""
         dev = k_all.device
         D, H, L = self.width, self.heads, k_all.shape[0]
         f32 = dict(device=dev, dtype=torch.float32)
@@ -282,6 +283,8 @@ class Decoder(nn.Module):
         ws = new(capi.decoder_attn_bwd_workspace_bytes(B, T, H) // 4)
         has_pos = "positional_embedding" in w
         dpos_total = torch.zeros(T, D, **f32) if has_pos else None
+        dk_all = torch.empty_like(k_all) if want_dkv else None
+        dv_all = torch.empty_like(v_all) if want_dkv else None
         for i in reversed(range(L)):
             pre = f"transformer.resblocks.{i}."
             sv = saved["blocks"][i]
@@ -300,7 +303,8 @@ class Decoder(nn.Module):
             dmix = lin_bwd(pre + "attn.out_proj.", dx, sv["mix"])
             dq = new(B, 2 * D)
             dpos = new(T, D) if has_pos else None
-            capi.decoder_attn_bwd(sv["q"], k_all[i], v_all[i], mask, dmix, sv["mix_s"], sv["stats"], dq, dpos, ws, B, T, P, H)
+            capi.decoder_attn_bwd(sv["q"], k_all[i], v_all[i], mask, dmix, sv["mix_s"], sv["stats"], dq, dpos, ws, B, T, P, H,
+                                  dk=dk_all[i] if want_dkv else None, dv=dv_all[i] if want_dkv else None)
             if has_pos:
                 dpos_total += dpos
             dh1 = lin_bwd(pre + "attn.in_proj.", dq, sv["h1"])
@@ -315,6 +319,8 @@ class Decoder(nn.Module):
         grads["class_embedding"] = dcls_rows.sum(dim=0)
         if has_pos:
             grads["positional_embedding"] = dpos_total.view(T, 1, H, D // H)
+        if want_dkv:
+            grads["__dk"], grads["__dv"] = dk_all, dv_all
         return grads
 
 
@@ -339,6 +345,7 @@ class _DecoderFn(torch.autograd.Function):
         d_raws, d_logits = list(d_rest[:n]), list(d_rest[n:2 * n])
         k_all, v_all, mask = ctx.kv
         B, T, P = ctx.dims
-        grads = ctx.dec._backward_kernels(ctx.w, ctx.saved, k_all, v_all, mask, B, T, P, d_feat, d_raws, d_logits)
+        want_dkv = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        grads = ctx.dec._backward_kernels(ctx.w, ctx.saved, k_all, v_all, mask, B, T, P, d_feat, d_raws, d_logits, want_dkv)
         out = [grads.get(nm) if rq else None for nm, rq in zip(ctx.names, ctx.req)]
-        return (None, None, None, None, None, None, *out)
+        return (None, grads.get("__dk"), grads.get("__dv"), None, None, None, *out)

@@ -177,12 +177,10 @@ class Detector(nn.Module):
         if self.adapter is None:
             kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos)
         else:
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.adapter.parameters()):
-                raise NotImplementedError("training a non-frozen CompInvAdapter is not built yet: freeze it "
-                                          "(adapter.frozen = 1) or run under torch.no_grad()")
-            # raw K/V export, then adapter(kv) + pos in place (models.py:546-549, :326-329)
+            # raw K/V export, then adapter(kv) + pos (models.py:546-549, :326-329); differentiable w.r.t. the
+            # adapter's parameters when they are trainable
             kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, None)
-            kv = self.adapter.apply_packed(kv[0], kv[1], t, pos)
+            kv = self.adapter.run(kv[0], kv[1], t, pos)
         _, video_features, task_logits = self.decoder.run(kv, m)
         features = {}
         if with_video_features:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DFD_ABI_VERSION 2
+#define DFD_ABI_VERSION 3
 
 enum { DFD_F32 = 0, DFD_BF16 = 1 };
 
@@ -56,6 +56,7 @@ typedef struct dfd_gemm_extra {
   void* v_export;
   int32_t tokens;          /* tokens per frame incl. CLS (197 for ViT-B/16) */
   int32_t frames_per_clip; /* T */
+  const void* residual;    /* RESIDUAL_POS: residual source in c_dtype with C's leading dimension; NULL = C (in place) */
 } dfd_gemm_extra;
 
 const char* dfd_last_error(void);          /* host pointer, valid until the thread's next failing call */
@@ -82,6 +83,14 @@ int dfd_patchify(const float* frames, void* patches, int out_dtype, int n_frames
 int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int ab_dtype, void* C, int64_t ldc,
              int c_dtype, const float* bias, int epilogue, const dfd_gemm_extra* extra, int64_t M, int N, int K,
              void* stream);
+
+/* C[Ma, Nb] (f32) = Aᵀ · B for tall row-major operands A [R, Ma], B [R, Nb] in `dtype` — the weight
+ * gradient of a Linear applied to R rows (adapter training: R = B·T·patches).  Internally: zero-padded
+ * transposes, a split-K pass of the general MFMA kernel into f32 slabs, fixed-order slab reduction
+ * (deterministic).  workspace >= dfd_gemm_at_b_workspace(...) bytes, 256-byte aligned. */
+size_t dfd_gemm_at_b_workspace(int64_t R, int Ma, int Nb, int dtype);
+int dfd_gemm_at_b(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C, int64_t R, int Ma, int Nb,
+                  void* workspace, void* stream);
 
 /* Encoder self-attention over the packed projection qkv [n_frames*tokens, 3*heads*head_dim]
  * (column blocks q | k | v; head h = columns h*head_dim ..): out = softmax(q kᵀ · scale) v,
@@ -131,20 +140,28 @@ int dfd_head_fwd(const float* x, int64_t ldx, const float* gamma, const float* b
 int dfd_adapter_norm_gelu(const void* a, void* y, int dtype, const float* weight, const float* bias, int frames,
                           int patches, int x, int joint, float eps, void* stream);
 
+/* Backward of dfd_adapter_norm_gelu: a = the forward's input, dy = dL/dy; writes da = dL/da (same dtype;
+ * must NOT alias dy: the affine pass re-reads dy) and the affine gradients dweight / dbias (shapes of weight / bias), summed over frames in
+ * a fixed order.  workspace >= dfd_adapter_norm_gelu_bwd_workspace(...) bytes. */
+size_t dfd_adapter_norm_gelu_bwd_workspace(int frames, int patches, int x, int joint);
+int dfd_adapter_norm_gelu_bwd(const void* a, const void* dy, void* da, int dtype, const float* weight, const float* bias,
+                              float* dweight, float* dbias, void* workspace, int frames, int patches, int x, int joint,
+                              float eps, void* stream);
+
 /* ---- decoder backward (the encoder is frozen: reference models.py:440, :501; these are the
  *      gradients `accelerator.backward` produces in the reference train step, trainer.py:157-165) ---- */
 
 /* Gradient of dfd_decoder_attn_fwd w.r.t. its query and, because the exported K/V are
  * `encoder_kv + temporal positional embedding` (models.py:326-329), w.r.t. that embedding:
  *   dq   f32 [B, heads, 2*d];  dpos f32 [T, heads*d] = Σ_{clip, patch} (dK + dV), or NULL;
- *   dk, dv f32 [B, S, heads*d] or NULL: the full key/value gradients (adapter training only);
+ *   dk, dv [B, S, heads*d] in dkv_dtype, or NULL: the full key/value gradients (adapter training only);
  *   dmix, mix_softmax [B, heads*d], stats [B, heads, 2] from the forward;
  *   workspace >= dfd_decoder_attn_bwd_workspace(B, T, heads, d) bytes. */
 size_t dfd_decoder_attn_bwd_workspace(int B, int T, int heads, int d);
 int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v, int kv_dtype, const uint8_t* frame_mask,
                          const float* dmix, const float* mix_softmax, const float* stats, float* dq, float* dpos,
-                         float* dk, float* dv, void* workspace, int B, int T, int patches, int heads, int d,
-                         void* stream);
+                         void* dk, void* dv, int dkv_dtype, void* workspace, int B, int T, int patches, int heads,
+                         int d, void* stream);
 
 /* dW[N,K] = dyᵀ x, db[N] = Σ_b dy (db may be NULL): weight gradient of dfd_linear_rows. */
 int dfd_linear_rows_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dW, float* db, int B,

@@ -134,7 +134,7 @@ def make_detector(case, precision):
     return det.to("cuda")
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_nopos", "tiny_augq", "small", "small14", "vitb16_cfg1"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_nopos", "tiny_augq", "tiny_adapter_nln", "tiny_adapter_ln", "small", "small14", "vitb16_cfg1"])
 def test_train_step_contract_matches_reference(name):
     """fp32 path: gradients of every decoder parameter after backward(mean loss), then two SGD steps
     on the same batch, against the reference's own autograd / optimizer results."""
@@ -199,3 +199,41 @@ def test_bf16_train_step_gradients_close_to_reference():
         assert cos > 0.999, (pn, cos)
     pos = params["decoder.positional_embedding"].grad.float().cpu()
     np.testing.assert_allclose(pos.norm().item(), g["grad0.decoder.positional_embedding.norm"], rtol=2e-2)
+
+
+@pytest.mark.parametrize("R,Ma,Nb", [(40, 8, 12), (777, 128, 32), (5000, 256, 768), (94080, 768, 256)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_at_b(capi, R, Ma, Nb, dtype):
+    """Weight-gradient primitive C = A^T B over R rows, deterministic split-K."""
+    a, b = rnd(R, Ma, seed=40), rnd(R, Nb, seed=41)
+    ar, br = (a, b) if dtype == torch.float32 else (a.bfloat16().float(), b.bfloat16().float())
+    want = ar.double().T @ br.double()
+    ws = torch.empty(capi.gemm_at_b_workspace_bytes(R, Ma, Nb, dtype) // 4 + 64, device="cuda")
+    c = torch.empty(Ma, Nb, device="cuda")
+    capi.gemm_at_b(a.to(dtype).cuda(), b.to(dtype).cuda(), c, ws)
+    close(c, want, 1e-3 * R ** 0.5, 1e-4, "A^T B")
+    c2 = torch.empty_like(c)
+    capi.gemm_at_b(a.to(dtype).cuda(), b.to(dtype).cuda(), c2, ws)
+    assert torch.equal(c, c2)
+
+
+@pytest.mark.parametrize("joint", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_adapter_norm_gelu_backward(capi, joint, dtype):
+    frames, P, x = 5, 196, 256
+    a = rnd(frames, P, x, seed=50, scale=1.5).to(dtype).float().requires_grad_(True)
+    shape = (P, x) if joint else (x,)
+    w = (1 + 0.1 * rnd(*shape, seed=51)).requires_grad_(True)
+    b = (0.1 * rnd(*shape, seed=52)).requires_grad_(True)
+    dy = rnd(frames, P, x, seed=53).to(dtype).float()
+    y = F.gelu(F.layer_norm(a, shape, w, b, 1e-5))
+    (y * dy).sum().backward()
+    ad, dyd = a.detach().to(dtype).cuda(), dy.to(dtype).cuda()
+    da = torch.empty_like(ad)
+    dw, db = torch.empty(*shape, device="cuda"), torch.empty(*shape, device="cuda")
+    ws = torch.empty(capi.adapter_norm_gelu_bwd_workspace_bytes(frames, P, x, joint) // 4 + 4, device="cuda")
+    capi.adapter_norm_gelu_bwd(ad, dyd, da, w.detach().cuda(), b.detach().cuda(), dw, db, ws, frames, P, x, joint)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    close(da, a.grad, tol, 1e-3 if dtype == torch.float32 else 2e-2, "da")
+    close(dw, w.grad, 1e-3 if dtype == torch.float32 else 5e-2, 1e-3, "dweight")
+    close(db, b.grad, 1e-3 if dtype == torch.float32 else 5e-2, 1e-3, "dbias")
