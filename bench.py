@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=-1, help="HIP streams for independent frame chunks (-1 = package default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--adapter", default="none", choices=["none", "nln", "z0", "ln"],
+                    help="CompInvAdapter 768-x-768-<struct>, x = 256 (every configs/deepfake/*.yaml enables one); default none = headline")
     return ap.parse_args()
 
 
@@ -63,6 +65,9 @@ def build_model(args, device):
         cfg.decode_mode, cfg.decode_indices = "index", [6, 7, 8, 9, 10, 11]  # every configs/deepfake/*.yaml
     else:
         cfg.decode_mode, cfg.decode_stride = "stride", 2
+    if args.adapter != "none":
+        from dfd_clip_amd.config import ConfigNode
+        cfg.adapter = ConfigNode({"type": "normal", "frozen": 0, "struct": {"type": f"768-x-768-{args.adapter}", "x": 256}})
     sd = random_state_dict(cfg, args.frames, seed=0)
     det = Detector(cfg, args.frames, None, precision=args.precision)
     det.load_state_dict(sd)
@@ -210,7 +215,7 @@ def main():
                                     f"BASELINE configs[1]: {args.arch} forward-only Detector.predict (inference.py path)")
                                    + f", {B} clips x {T} frames x 3x{res}x{res} per GPU, decode layers {det.layer_indices}, "
                                      f"random-init weights, inputs resident in HBM",
-                       "mode": args.mode, "clips_per_gpu": B, "frames_per_clip": T, "frame_chunk": det.encoder.frame_chunk,
+                       "mode": args.mode, "adapter": args.adapter, "clips_per_gpu": B, "frames_per_clip": T, "frame_chunk": det.encoder.frame_chunk,
                        "streams": det.encoder.streams},
             "roofline": {"bound": "mfma", "kernel": "c_fc GEMM + QuickGELU (M=%d, N=%d, K=%d)" % (launch_m, 4 * width, width),
                          "achieved": round(achieved, 2) if achieved else None, "peak": peak, "unit": "TFLOP/s",

@@ -14,6 +14,11 @@ libdfdclip_hip.so; PyTorch supplies device memory, streams and the tiny per-samp
 import contextlib
 import logging
 import os
+import random
+from itertools import combinations
+from math import comb
+
+import numpy as np
 
 import torch
 from torch import nn
@@ -159,11 +164,23 @@ class Detector(nn.Module):
         else:
             raise NotImplementedError()
         self.transform = ClipTransform(self.encoder.input_resolution)
-        for key in ("patch_mask", "compression", "nerf_raw", "temporal"):
+        # trainable extras (reference models.py:488-496)
+        if "temporal" in self.train_mode and self.train_mode.temporal == "ranking":
+            self.ranking_transform_param = nn.Parameter((self.encoder.width ** -0.5) * torch.randn(self.encoder.width, 1),
+                                                        requires_grad=True)
+        for key in ("compression", "nerf_raw"):
             if key in self.train_mode:
-                raise NotImplementedError(f"train_mode.{key} is not built yet (SURVEY.md §8f rank 4)")
-        if "ema_frame" in self.op_mode and self.op_mode.ema_frame:
-            raise NotImplementedError("op_mode.ema_frame is not built yet (SURVEY.md §8f rank 4)")
+                # unreachable upstream: the reference's compression branch unpacks five dims from K/V that its decoder
+                # has already flattened to four (models.py:604 -> ValueError) and nerf_raw reads `_b`, defined only
+                # there (models.py:673 -> NameError); there is no behaviour to match
+                raise NotImplementedError(f"train_mode.{key}: this branch raises in the reference itself (models.py:604, :673)")
+        if "patch_mask" in self.train_mode:
+            if self.train_mode.patch_mask.type not in ("batch", "sample"):
+                # "guide" reads a pickled saliency map (models.py:494-496): unpickling foreign files is not done here
+                raise NotImplementedError(f"patch_mask.type={self.train_mode.patch_mask.type} is not built")
+            if self.adapter is not None and self.adapter.struct.endswith("nln"):
+                raise NotImplementedError("patch_mask with the nln adapter: its LayerNorm is sized for all patches "
+                                          "(the reference fails on this combination too)")
 
     def predict(self, x, m, with_video_features=False, with_adapt_features=False, train=False):
         """x [B,T,3,R,R], m [B,T] bool -> (task_logits list of [B,out_dim] with L2 norm 5, features)."""
@@ -174,8 +191,34 @@ class Detector(nn.Module):
         # the encoder is frozen and runs without autograd (reference models.py:440, :501); the decoder is
         # differentiable w.r.t. its own parameters
         pos = self.decoder.temporal_pos()
-        if self.adapter is None:
+        masked = train and "patch_mask" in self.train_mode
+        if self.adapter is None and not masked:
             kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos)
+        elif masked:
+            # keep a random subset of patch positions per layer (models.py:511-544): "batch" draws once for all
+            # layers, "sample" per layer.  The raw export is row-gathered, then adapter / positional add follow.
+            kr, vr = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, None)
+            P = kr.shape[1] // (b * t)
+            num_select = int(P * self.train_mode.patch_mask.ratio)
+            ks, vs, idx = [], [], None
+            for i in range(len(self.layer_indices)):
+                if idx is None or self.train_mode.patch_mask.type == "sample":
+                    idx = torch.as_tensor(np.random.choice(range(P), num_select, replace=False), device=kr.device)
+                ks.append(kr[i].view(b * t, P, -1).index_select(1, idx).reshape(b * t * num_select, -1))
+                vs.append(vr[i].view(b * t, P, -1).index_select(1, idx).reshape(b * t * num_select, -1))
+            kr, vr = torch.stack(ks), torch.stack(vs)
+            if self.adapter is not None:
+                self.adapter.patches = num_select
+                try:
+                    kv = self.adapter.run(kr, vr, t, pos)
+                finally:
+                    self.adapter.patches = (self.encoder.input_resolution // self.encoder.patch_size) ** 2
+            else:
+                if pos is not None:  # the decoder's positional add on the gathered rows (models.py:326-329)
+                    pp = pos.to(kr.dtype).view(1, 1, t, 1, -1)
+                    kr = (kr.view(len(ks), b, t, num_select, -1) + pp).view_as(kr)
+                    vr = (vr.view(len(vs), b, t, num_select, -1) + pp).view_as(vr)
+                kv = (kr.contiguous(), vr.contiguous())
         else:
             # raw K/V export, then adapter(kv) + pos (models.py:546-549, :326-329); differentiable w.r.t. the
             # adapter's parameters when they are trainable
@@ -197,14 +240,56 @@ class Detector(nn.Module):
         return task_logits, features
 
     def forward(self, x, y, m, comp=None, speed=None, train=False, single_task=None, *args, **kargs):
+        b, t, c, h, w = x.shape
+        if "ema_frame" in self.op_mode and self.op_mode.ema_frame:
+            # exponential moving average of the frames -> one frame per clip (models.py:572-578)
+            r = self.op_mode.ema_frame
+            _x = torch.zeros((b, 1, c, h, w), device=x.device)
+            for i in range(t):
+                _x = _x * r + x[:, i].unsqueeze(1) * (1 - r)
+            x, m = _x, m[:, 0].unsqueeze(1)
         task_logits, features = self.predict(x, m, with_video_features=True, train=train)
+        video_features = features["video"]
         task_losses = [
             loss_fn(logits, labels) if single_task == None or i == single_task else 0
             for i, loss_fn, logits, labels in zip(range(len(self.losses)), self.losses, task_logits, y)
         ]
         if not train:
             return task_losses, task_logits
-        return task_losses, task_logits, {}
+        return task_losses, task_logits, self._other_losses(task_losses, video_features, features, comp, speed, b, x.device)
+
+    def _other_losses(self, task_losses, video_features, features, comp, speed, b, device):
+        """Auxiliary training losses of the reference that are reachable there (temporal ranking / triplet,
+        models.py:680-736), on the [B, D] video features: plain torch arithmetic on small tensors,
+        differentiable through the HIP autograd nodes."""
+        other = {}
+        F_ = torch.nn.functional
+        if "temporal" in self.train_mode:
+            order = torch.argsort(speed, descending=True).tolist()
+            if self.train_mode.temporal == "ranking":  # faster clips must score higher (models.py:684-704)
+                z = (video_features @ self.ranking_transform_param).squeeze()
+                parts = []
+                for rk in range(b - 1):
+                    hi = z[order[rk]].repeat(b - 1 - rk)
+                    lo = z[order[rk + 1:], ...]
+                    parts.append(F_.margin_ranking_loss(hi, lo, torch.ones(b - 1 - rk, device=device), reduction="none"))
+                other["speed/rank"] = 0.05 * torch.cat(parts).mean()
+            elif self.train_mode.temporal == "triplet":  # models.py:706-733
+                rounds = min(comb(b, 3), 10)
+                ids = list(range(b))
+                random.shuffle(ids)
+                trip = iter(combinations(ids, 3))
+                loss = torch.tensor(0.0, device=device)
+                for _ in range(rounds):
+                    a_, p_, n_ = sorted(next(trip), key=lambda j: order.index(j))
+                    loss = loss + F_.triplet_margin_loss(anchor=video_features[a_], positive=video_features[p_],
+                                                         negative=video_features[n_], margin=torch.abs(speed[n_] - speed[p_]))
+                    loss = loss + F_.triplet_margin_loss(anchor=video_features[n_], positive=video_features[p_],
+                                                         negative=video_features[a_], margin=torch.abs(speed[p_] - speed[a_]))
+                other["speed/triplet"] = 0.01 * loss / (rounds * 2)
+            else:
+                raise NotImplementedError()
+        return other
 
     def configure_optimizers(self, lr):
         params = [p for p in self.parameters() if p.requires_grad]

@@ -175,6 +175,8 @@ def random_state_dict(config, num_frames, seed=0):
                          "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias"):
                 sd[f"decoder.transformer.resblocks.{b}.{part}"] = \
                     sd[f"encoder.transformer.resblocks.{l}.{part}"].clone()
+    if "temporal" in config.train_mode and config.train_mode.temporal == "ranking":
+        sd["ranking_transform_param"] = _fill(rng, "proj", (width, 1))
     if config.adapter.type != "none":
         st = config.adapter.struct
         for k, shp in adapter_schema(arch, len(lidx), st.type, int(st.x)).items():

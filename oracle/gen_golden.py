@@ -127,7 +127,14 @@ CASES = {
     "small": ("small", 2, 3, dict(decode_mode="index", decode_indices=[1, 2]), "medium"),
     "small14": ("small14", 2, 3, dict(decode_mode="index", decode_indices=[0, 1]), "medium"),
     "vitb16_cfg1": ("ViT-B/16", 2, 8, dict(decode_mode="index", decode_indices=[6, 7, 8, 9, 10, 11]), "slices"),
+    # training-mode extras (reference models.py:511-544, :572-578, :598-736)
+    "tiny_ema": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], op_mode__ema_frame=0.3,
+                                    op_mode__temporal_position=0), "light"),
+    "tiny_rank": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], train_mode__temporal="ranking"), "light"),
+    "tiny_pmask": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1],
+                                      train_mode__patch_mask={"type": "batch", "ratio": 0.5}), "light"),
 }
+EXTRA_INPUTS = dict(comp=["raw", "c23"], speed=[1.0, 2.5], np_seed=11)
 
 
 def run_case(name, mm, Acc, to_cn):
@@ -151,7 +158,8 @@ def run_case(name, mm, Acc, to_cn):
     out["logits"] = logits[0].numpy()
     out["losses"] = losses[0].numpy()
     out["video_feature"] = feats["video"].numpy()
-    assert torch.equal(plog[0], logits[0])
+    if "ema_frame" not in str(over):  # forward() averages the frames first (models.py:572-578), predict() does not
+        assert torch.equal(plog[0], logits[0])
     lidx = det.layer_indices
     out["layer_indices"] = np.asarray(lidx)
     if store == "full":
@@ -178,9 +186,15 @@ def run_case(name, mm, Acc, to_cn):
     det.train()
     opt = det.configure_optimizers(0.01)
     step_losses = []
+    speed = torch.tensor(EXTRA_INPUTS["speed"])
     for step in range(2):
         opt.zero_grad()
-        tl, tz, other = det(x, [y], m, train=True, single_task=0)
+        np.random.seed(EXTRA_INPUTS["np_seed"] + step)
+        tl, tz, other = det(x, [y], m, EXTRA_INPUTS["comp"], speed, train=True, single_task=0)
+        if step == 0:
+            out["train_task_loss"] = tl[0].detach().numpy().copy()
+            for k_, v_ in other.items():
+                out["other." + k_] = np.asarray(v_.detach().item())
         loss = tl[0].mean() + sum(other.values())
         loss.backward()
         if step == 0:

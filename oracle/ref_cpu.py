@@ -209,9 +209,22 @@ def detector_predict(w, x, m, *, heads, patch, layer_indices, out_dims, num_fram
     return logits, feat
 
 
-def detector_forward_eval(w, x, y_list, m, single_task=None, **kw):
+def ema_frames(x, m, ratio):
+    """`op_mode.ema_frame` (reference `src/models.py:572-578`): exponential moving average over the
+    frames, started from zeros -> one frame per clip; the mask keeps its first column."""
+    b, t, c, h, wd = x.shape
+    acc = torch.zeros((b, 1, c, h, wd))
+    for i in range(t):
+        acc = acc * ratio + x[:, i].unsqueeze(1) * (1 - ratio)
+    return acc, m[:, 0].unsqueeze(1)
+
+
+def detector_forward_eval(w, x, y_list, m, single_task=None, ema_frame=0, **kw):
     """`Detector.forward(train=False)` (reference `src/models.py:568-596`): per-task
     unreduced losses (0 for unselected tasks) and logits."""
+    if ema_frame:
+        x, m = ema_frames(x, m, ema_frame)
+        kw = dict(kw, num_frames=1)
     logits, _ = detector_predict(w, x, m, **kw)
     losses = [cross_entropy_per_sample(z, y) if (single_task is None or i == single_task) else 0
               for i, (z, y) in enumerate(zip(logits, y_list))]

@@ -25,7 +25,13 @@ CASES = {
     "small": ("small", 2, 3, dict(decode_mode="index", decode_indices=[1, 2])),
     "small14": ("small14", 2, 3, dict(decode_mode="index", decode_indices=[0, 1])),
     "vitb16_cfg1": ("ViT-B/16", 2, 8, dict(decode_mode="index", decode_indices=[6, 7, 8, 9, 10, 11])),
+    "tiny_ema": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], op_mode__ema_frame=0.3,
+                                    op_mode__temporal_position=0)),
+    "tiny_rank": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], train_mode__temporal="ranking")),
+    "tiny_pmask": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1],
+                                      train_mode__patch_mask={"type": "batch", "ratio": 0.5})),
 }
+EXTRA_INPUTS = dict(comp=["raw", "c23"], speed=[1.0, 2.5], np_seed=11)
 
 
 def make_config(arch, **over):

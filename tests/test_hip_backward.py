@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import ref_cpu
-from tests.cases import build_case, load_golden
+from tests.cases import EXTRA_INPUTS, build_case, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -237,3 +237,40 @@ def test_adapter_norm_gelu_backward(capi, joint, dtype):
     close(da, a.grad, tol, 1e-3 if dtype == torch.float32 else 2e-2, "da")
     close(dw, w.grad, 1e-3 if dtype == torch.float32 else 5e-2, 1e-3, "dweight")
     close(db, b.grad, 1e-3 if dtype == torch.float32 else 5e-2, 1e-3, "dbias")
+
+
+@pytest.mark.parametrize("name", ["tiny_ema", "tiny_rank", "tiny_pmask"])
+def test_training_extras_match_reference(name):
+    """ema_frame (models.py:572-578), temporal ranking loss (:684-704) and the random patch mask (:511-544, same
+    numpy seed as the reference run): eval logits, train losses, auxiliary losses and gradients vs the reference."""
+    case = build_case(name)
+    g = load_golden(name)
+    det = make_detector(case, "fp32")
+    x, m, y = case["x"].cuda(), case["m"].cuda(), case["y"].cuda()
+    det.eval()
+    with torch.no_grad():
+        losses, logits = det(x, [y], m, single_task=0)
+    np.testing.assert_allclose(logits[0].cpu().numpy(), g["logits"], atol=1e-4)
+    np.testing.assert_allclose(losses[0].cpu().numpy(), g["losses"], atol=1e-4)
+    det.train()
+    speed = torch.tensor(EXTRA_INPUTS["speed"], device="cuda")
+    np.random.seed(EXTRA_INPUTS["np_seed"])
+    tl, tz, other = det(x, [y], m, EXTRA_INPUTS["comp"], speed, train=True, single_task=0)
+    np.testing.assert_allclose(tl[0].detach().cpu().numpy(), g["train_task_loss"], atol=1e-4)
+    for k_, v_ in other.items():
+        np.testing.assert_allclose(v_.item(), g["other." + k_], atol=1e-5, err_msg=k_)
+    assert {("other." + k_) for k_ in other} == {f for f in g.files if f.startswith("other.")}
+    (tl[0].mean() + sum(other.values())).backward()
+    checked = 0
+    for pn, p in det.named_parameters():
+        if p.grad is None:
+            continue
+        gr = p.grad.detach().float().cpu()
+        if "grad0." + pn in g.files:
+            want = torch.from_numpy(g["grad0." + pn])
+            scale = max(want.abs().max().item(), 1e-6)
+            assert (gr - want).abs().max().item() <= 1e-3 * scale + 2e-7, (pn, (gr - want).abs().max().item(), scale)
+        else:
+            np.testing.assert_allclose(gr.norm().item(), g["grad0." + pn + ".norm"], rtol=1e-3)
+        checked += 1
+    assert checked > 20
