@@ -27,11 +27,13 @@ int main() {
     hipMemcpy(W, h.data(), (size_t)sh.N * sh.K * 2, hipMemcpyHostToDevice);
     hipMemset(bias, 0, sh.N * 4); hipMemset(C, 0, M * sh.N * 4);
     GemmArgs a{}; a.A = A; a.W = W; a.C = C; a.bias = bias; a.lda = sh.K; a.ldw = sh.K; a.ldc = sh.N; a.M = M; a.N = sh.N; a.K = sh.K;
+    for (int i = 0; i < 20; ++i) lab_full(a, sh.cdt, sh.epi, 0);  // warm-up: clocks, caches, lazy code load (the first
+    hipDeviceSynchronize();                                       // variant measured used to read ~10 % low without it)
     for (auto& v : vars) {
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
       for (int i = 0; i < 3; ++i) v.fn(a, sh.cdt, sh.epi, 0);
       hipEventRecord(e0, 0);
-      const int it = 10;
+      const int it = 20;
       for (int i = 0; i < it; ++i) v.fn(a, sh.cdt, sh.epi, 0);
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); ms /= it;
