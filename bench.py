@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--ingest", default="f32", choices=["f32", "u8"],
+                    help="f32: frames already transformed (the headline's input); u8: raw uint8 frames through the ingest kernel")
+    ap.add_argument("--ingest-size", type=int, nargs=2, default=None, metavar=("H", "W"),
+                    help="with --ingest u8: source frame size (default = the model's resolution, i.e. no resize)")
     ap.add_argument("--adapter", default="none", choices=["none", "nln", "z0", "ln"],
                     help="CompInvAdapter 768-x-768-<struct>, x = 256 (every configs/deepfake/*.yaml enables one); default none = headline")
     return ap.parse_args()
@@ -133,7 +137,11 @@ def main():
     res, patch, width, _, heads, _ = ARCHS[args.arch]
     B, T = args.clips, args.frames
     g = torch.Generator(device=device).manual_seed(1234 + rank)
-    x = torch.randn(B, T, 3, res, res, device=device, generator=g)
+    if args.ingest == "u8":
+        ih, iw = args.ingest_size or (res, res)
+        x = torch.randint(0, 256, (B, T, 3, ih, iw), device=device, generator=g, dtype=torch.uint8)
+    else:
+        x = torch.randn(B, T, 3, res, res, device=device, generator=g)
     m = torch.ones(B, T, dtype=torch.bool, device=device)
     tokens = (res // patch) ** 2 + 1
     M = B * T * tokens
@@ -215,7 +223,7 @@ def main():
             "metric": f"1-sec clips/sec (30x224x224 frames) {args.arch}", "value": round(world * B * args.steps / dt, 3),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic" if args.ingest == "f32" else "synthetic uint8 frames %dx%d" % tuple(x.shape[-2:]),
             "config": {"workload": (f"BASELINE configs[2] (fwd+bwd): {args.arch} train step = frozen-encoder forward + decoder "
                                     f"forward/backward + SGD step" + (" + RCCL gradient all-reduce" if world > 1 else "")
                                     if args.mode == "train" else

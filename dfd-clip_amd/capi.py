@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT, EPI_RESIDUAL_POS = range(6)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -36,6 +36,9 @@ SIGNATURES = {
     "dfd_device_check": (c_int, []),
     "dfd_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_float, c_void_p]),
     "dfd_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dfd_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float),
+                                  c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dfd_preprocess_geometry": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "dfd_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int,
                          POINTER(GemmExtra), c_int64, c_int, c_int, c_void_p]),
     "dfd_gemm_at_b_workspace": (c_size_t, [c_int64, c_int, c_int, c_int]),
@@ -128,6 +131,33 @@ def patchify(frames, out, res, patch):
     n = frames.shape[0]
     _check(load_library().dfd_patchify(_ptr(frames), _ptr(out), _DTYPE[out.dtype], n, res, patch, out.shape[1], _stream()),
            "dfd_patchify")
+    return out
+
+
+def preprocess_geometry(in_h, in_w, res):
+    """(resized_h, resized_w, crop_top, crop_left) of `preprocess_u8`."""
+    v = [c_int() for _ in range(4)]
+    _check(load_library().dfd_preprocess_geometry(in_h, in_w, res, *[ctypes.byref(i) for i in v]), "dfd_preprocess_geometry")
+    return tuple(i.value for i in v)
+
+
+def preprocess_u8(frames, out, res, patch, mean, std, antialias=True, patch_rows=True):
+    """uint8 frames [n,3,H,W] -> normalised patch rows [n*P, kpad] (`patch_rows`) or frames
+    [n,3,res,res]; the device-side `Detector._transform` (reference `src/models.py:756-768`)."""
+    _dev(frames, out)
+    assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[1] == 3
+    assert frames.is_contiguous() and out.is_contiguous()
+    n, _, h, w = frames.shape
+    m3 = (c_float * 3)(*[float(v) for v in mean])
+    s3 = (c_float * 3)(*[float(v) for v in std])
+    if patch_rows:
+        assert out.dim() == 2 and out.shape[0] == n * (res // patch) ** 2
+        kpad = out.shape[1]
+    else:
+        assert tuple(out.shape) == (n, 3, res, res)
+        kpad = 0
+    _check(load_library().dfd_preprocess_u8(_ptr(frames), n, h, w, res, patch, int(bool(antialias)), m3, s3, _ptr(out),
+                                            _DTYPE[out.dtype], 1 if patch_rows else 0, kpad, _stream()), "dfd_preprocess_u8")
     return out
 
 

@@ -95,23 +95,44 @@ def load_clip_visual(name, precision):
 
 class ClipTransform:
     """Resize(bicubic, shorter side) -> CenterCrop -> float in [0,1] -> Normalize (reference
-    `src/models.py:756-768`), on tensors [T, 3, H, W] uint8 or float."""
+    `src/models.py:756-768`), on tensors [T, 3, H, W] uint8 or float.
+
+    uint8 frames already on the GPU go through the ingest kernel (`dfd_preprocess_u8`); anything
+    else takes the same arithmetic through torch ops (dataloader workers on the host).  Geometry
+    and rounding follow torchvision's tensor path: longer side int(n_px*long/short), a resized
+    uint8 image is rounded back to uint8, crop origin round((size - n_px)/2)."""
     MEAN = (0.48145466, 0.4578275, 0.40821073)
     STD = (0.26862954, 0.26130258, 0.27577711)
 
-    def __init__(self, n_px):
+    def __init__(self, n_px, antialias=True):
         self.n_px = n_px
+        self.antialias = antialias
+
+    def geometry(self, h, w):
+        s, l = (h, w) if h <= w else (w, h)
+        new_l = int(self.n_px * l / s)
+        nh, nw = (self.n_px, new_l) if h <= w else (new_l, self.n_px)
+        return nh, nw, int(round((nh - self.n_px) / 2.0)), int(round((nw - self.n_px) / 2.0))
 
     def __call__(self, frames):
         x = frames
-        if x.dtype == torch.uint8:
-            x = x.float() / 255.0
+        if x.is_cuda and x.dtype == torch.uint8:
+            lead = x.shape[:-3]
+            out = torch.empty(x.numel() // (3 * x.shape[-2] * x.shape[-1]), 3, self.n_px, self.n_px, device=x.device)
+            tile = max(d for d in range(1, 33) if self.n_px % d == 0)  # work tile of the kernel, any divisor
+            capi.preprocess_u8(x.reshape(-1, *x.shape[-3:]).contiguous(), out, self.n_px, tile, self.MEAN, self.STD,
+                               antialias=self.antialias, patch_rows=False)
+            return out.view(*lead, 3, self.n_px, self.n_px)
+        was_u8 = x.dtype == torch.uint8
         h, w = x.shape[-2:]
-        s = self.n_px / min(h, w)
-        nh, nw = max(self.n_px, round(h * s)), max(self.n_px, round(w * s))
-        x = torch.nn.functional.interpolate(x, size=(nh, nw), mode="bicubic", antialias=True, align_corners=False)
-        top, left = (nh - self.n_px) // 2, (nw - self.n_px) // 2
+        nh, nw, top, left = self.geometry(h, w)
+        if (nh, nw) != (h, w):
+            x = torch.nn.functional.interpolate(x.float(), size=(nh, nw), mode="bicubic", antialias=self.antialias,
+                                                align_corners=False)
+            if was_u8:
+                x = x.round().clamp(0, 255)
         x = x[..., top:top + self.n_px, left:left + self.n_px]
+        x = x.float() / 255.0 if was_u8 else x
         mean = torch.tensor(self.MEAN, device=x.device).view(1, 3, 1, 1)
         std = torch.tensor(self.STD, device=x.device).view(1, 3, 1, 1)
         return (x - mean) / std
@@ -242,6 +263,9 @@ class Detector(nn.Module):
     def forward(self, x, y, m, comp=None, speed=None, train=False, single_task=None, *args, **kargs):
         b, t, c, h, w = x.shape
         if "ema_frame" in self.op_mode and self.op_mode.ema_frame:
+            if x.dtype == torch.uint8:
+                x = self.transform(x)
+                h, w = x.shape[-2:]
             # exponential moving average of the frames -> one frame per clip (models.py:572-578)
             r = self.op_mode.ema_frame
             _x = torch.zeros((b, 1, c, h, w), device=x.device)

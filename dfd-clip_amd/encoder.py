@@ -101,6 +101,11 @@ class VisionTransformer(nn.Module):
         # keeps per-kernel timings meaningful
         self.streams = 1
         self._side_streams = []
+        # uint8 ingest (`Detector._transform`, reference models.py:756-768): CLIP's normalisation constants;
+        # antialias follows current torchvision's tensor default (older releases resized without it)
+        self.pixel_mean = (0.48145466, 0.4578275, 0.40821073)
+        self.pixel_std = (0.26862954, 0.26130258, 0.27577711)
+        self.antialias = True
 
     # ---- derived device-side operands ---------------------------------------------------
     @property
@@ -174,11 +179,26 @@ class VisionTransformer(nn.Module):
         return ws
 
     # ---- kernels sequence ---------------------------------------------------------------
+    def _as_frames(self, x):
+        """f32 frames [N,3,R,R] already transformed, or uint8 frames [N,3,H,W] straight from the
+        video reader (any H, W): those are resized / cropped / normalised by the ingest kernel."""
+        if x.dtype == torch.uint8:
+            assert x.dim() == 4 and x.shape[1] == 3, "uint8 frames must be [N, 3, H, W]"
+            return x.contiguous()
+        assert tuple(x.shape[1:]) == (3, self.input_resolution, self.input_resolution), \
+            f"frames must be [N, 3, {self.input_resolution}, {self.input_resolution}]"
+        return x.to(torch.float32).contiguous()
+
     def _embed(self, frames, ws, p):
         """conv1 as patchify + GEMM, CLS row, + positional embedding, ln_pre (model.py:277-292)."""
         n = frames.shape[0]
         P, D = self.tokens - 1, self.width
-        capi.patchify(frames, ws["patches"], self.input_resolution, self.patch_size)
+        if frames.dtype == torch.uint8:
+            # raw video frames: Resize/CenterCrop/Normalize (`Detector._transform`) happen in the ingest kernel
+            capi.preprocess_u8(frames, ws["patches"][:n * P], self.input_resolution, self.patch_size, self.pixel_mean,
+                               self.pixel_std, antialias=self.antialias)
+        else:
+            capi.patchify(frames, ws["patches"], self.input_resolution, self.patch_size)
         capi.gemm(ws["patches"], p["w_patch"], ws["x"], None, capi.EPI_PATCH_EMBED, m=n * P, pos=p["pos"], cls=p["cls"],
                   tokens=self.tokens)
         M = n * self.tokens
@@ -210,7 +230,7 @@ class VisionTransformer(nn.Module):
         if not x.is_cuda:
             raise capi.DfdError("the encoder runs on HIP kernels only: pass device tensors")
         p = self._prepare()
-        frames = x.to(torch.float32).contiguous()
+        frames = self._as_frames(x)
         n = frames.shape[0]
         D, H, tok = self.width, self.heads, self.tokens
         M = n * tok
@@ -238,7 +258,7 @@ class VisionTransformer(nn.Module):
         if not x.is_cuda:
             raise capi.DfdError("the encoder runs on HIP kernels only: pass device tensors")
         p = self._prepare()
-        frames = x.to(torch.float32).contiguous()
+        frames = self._as_frames(x)
         n = frames.shape[0]
         assert n % num_frames == 0
         D, tok = self.width, self.tokens

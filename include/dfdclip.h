@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DFD_ABI_VERSION 3
+#define DFD_ABI_VERSION 4
 
 enum { DFD_F32 = 0, DFD_BF16 = 1 };
 
@@ -75,6 +75,21 @@ int dfd_layernorm(const float* x, int64_t ldx, const float* gamma, const float* 
  * >= 3*patch*patch zero-filled.  The patch conv (clip/model.py:264, :277) then is a plain GEMM. */
 int dfd_patchify(const float* frames, void* patches, int out_dtype, int n_frames, int res, int patch, int kpad,
                  void* stream);
+
+/* Device-side `Detector._transform` for uint8 frames (src/models.py:756-768: Resize(res, BICUBIC)
+ * -> CenterCrop(res) -> ConvertImageDtype(float32) -> Normalize(mean, std)), fused with the patch
+ * extraction of dfd_patchify.  frames: [n_frames, 3, in_h, in_w] uint8 (device).  The shorter
+ * side is resized to `res` (longer side int(res*long/short), as torchvision), the resized image is
+ * rounded back to the uint8 grid and clamped (skipped when no resize is needed), centre-cropped
+ * (offset round-half-even((size-res)/2)), divided by 255 and normalised per channel.
+ * antialias 0: ATen upsample_bicubic2d (A=-0.75); 1: _upsample_bicubic2d_aa (A=-0.5).
+ * mean3 / std3: HOST pointers to 3 floats.  layout 0: out = frames [n,3,res,res]; layout 1: out =
+ * patch rows [n*P, kpad] exactly as dfd_patchify writes them.  out_dtype DFD_F32 or DFD_BF16. */
+int dfd_preprocess_u8(const uint8_t* frames, int n_frames, int in_h, int in_w, int res, int patch, int antialias,
+                      const float* mean3, const float* std3, void* out, int out_dtype, int layout, int kpad,
+                      void* stream);
+/* The geometry dfd_preprocess_u8 uses: resized size and crop origin (host-only helper). */
+int dfd_preprocess_geometry(int in_h, int in_w, int res, int* rs_h, int* rs_w, int* top, int* left);
 
 /* C = epilogue(A[M,K] · W[N,K]ᵀ): A and W row-major in ab_dtype with leading dimensions lda / ldw
  * (elements), fp32 accumulation on the matrix cores (bf16: v_mfma_f32_32x32x16_bf16 /

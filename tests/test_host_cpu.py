@@ -94,3 +94,35 @@ def test_adapter_state_dict_schema():
     assert set(det.state_dict().keys()) == set(case["sd"].keys())
     det.load_state_dict(case["sd"])
     assert det.adapter.l0_k[1].weight.shape == (4, 32)
+
+
+def test_clip_transform_geometry_and_host_path():
+    """`ClipTransform` (reference `src/models.py:756-768`): torchvision's geometry rules (longer
+    side truncated, crop origin rounded half to even) and the uint8 re-quantisation after a
+    resize; the C helper `dfd_preprocess_geometry` must agree (host-only call, no GPU)."""
+    import ctypes
+
+    import torch
+    from dfd_clip_amd import capi
+    from dfd_clip_amd.detector import ClipTransform
+    t = ClipTransform(224)
+    assert t.geometry(224, 224) == (224, 224, 0, 0)
+    assert t.geometry(224, 225) == (224, 225, 0, 0)       # round(0.5) = 0
+    assert t.geometry(224, 227) == (224, 227, 0, 2)       # round(1.5) = 2
+    assert t.geometry(480, 853) == (224, 398, 0, 87)      # int(224*853/480) = 398
+    assert t.geometry(1920, 1080) == (398, 224, 87, 0)
+    lib = capi.load_library()
+    for h, w in [(224, 224), (224, 225), (224, 227), (480, 853), (1920, 1080), (97, 131), (640, 360)]:
+        v = [ctypes.c_int() for _ in range(4)]
+        assert lib.dfd_preprocess_geometry(h, w, 224, *[ctypes.byref(i) for i in v]) == 0
+        assert tuple(i.value for i in v) == t.geometry(h, w)
+    # no resize: exactly (u8/255 - mean)/std
+    g = torch.Generator().manual_seed(0)
+    u8 = torch.randint(0, 256, (2, 3, 224, 224), generator=g, dtype=torch.uint8)
+    want = (u8.float() / 255.0 - torch.tensor(t.MEAN).view(1, 3, 1, 1)) / torch.tensor(t.STD).view(1, 3, 1, 1)
+    assert torch.equal(t(u8), want)
+    # resize: output pixels sit on the uint8 grid
+    out = ClipTransform(32)(torch.randint(0, 256, (1, 3, 50, 70), generator=g, dtype=torch.uint8))
+    assert out.shape == (1, 3, 32, 32)
+    lv = (out * torch.tensor(t.STD).view(1, 3, 1, 1) + torch.tensor(t.MEAN).view(1, 3, 1, 1)) * 255.0
+    assert (lv - lv.round()).abs().max() < 1e-3
