@@ -54,6 +54,7 @@ template <typename T>
 __global__ __launch_bounds__(1024) void decoder_attn_partial_kernel(const float* __restrict__ q, const T* __restrict__ k,
                                                                     const T* __restrict__ v,
                                                                     const uint8_t* __restrict__ frame_mask,
+                                                                    const float* __restrict__ ext_w,
                                                                     float* __restrict__ ws, int splits, int T_frames,
                                                                     int patches, int heads, int R) {
   extern __shared__ float red[];  // [R][tpr][18]
@@ -99,15 +100,21 @@ __global__ __launch_bounds__(1024) void decoder_attn_partial_kernel(const float*
     dc = group8_sum(dc);
     l1 = group8_sum(l1);
     if (mb[s / patches]) {
-      if (ds > mx) {
-        const float alpha = __expf(mx - ds);
-        l *= alpha;
+      float p;
+      if (ext_w != nullptr) {
+        // attn_mode: the softmax-branch weight was computed by the grouped-softmax pass
+        p = ext_w[((int64_t)b * heads + hd) * S + s];
+      } else {
+        if (ds > mx) {
+          const float alpha = __expf(mx - ds);
+          l *= alpha;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) as[e] *= alpha;
-        mx = ds;
+          for (int e = 0; e < 8; ++e) as[e] *= alpha;
+          mx = ds;
+        }
+        p = __expf(ds - mx);
+        l += p;
       }
-      const float p = __expf(ds - mx);
-      l += p;
       const float gate = 2.0f / (1.0f + __expf(l1 * 0.125f));  // 2·sigmoid(−l1/√d)
       const float c = fast_tanh(dc) * gate;
 #pragma unroll
@@ -116,6 +123,10 @@ __global__ __launch_bounds__(1024) void decoder_attn_partial_kernel(const float*
         ac[e] = fmaf(c, vv[e], ac[e]);
       }
     }
+  }
+  if (ext_w != nullptr) {  // weights are final: neutral softmax state, unit normaliser counted once
+    mx = 0.f;
+    l = (split == 0 && rs == 0) ? 1.f : 0.f;
   }
   // merge the R row slots through LDS
   float* mine = red + ((size_t)rs * tpr + tr) * 18;
@@ -168,6 +179,84 @@ __global__ void decoder_attn_combine_kernel(const float* __restrict__ ws, float*
     stats[((int64_t)b * heads + hd) * 2 + 0] = M;
     stats[((int64_t)b * heads + hd) * 2 + 1] = L;
   }
+}
+
+// out[b, h, s] = scale * Σ_c a[b, h, c] · X[b, s, h*64 + c]  (a: `a_stride` floats per head); keys of
+// padded frames get `fill` when a mask is given.  Same lane mapping as the partial kernel.
+template <typename T>
+__global__ __launch_bounds__(1024) void decoder_rowdot_kernel(const float* __restrict__ a, int a_stride,
+                                                              const T* __restrict__ X,
+                                                              const uint8_t* __restrict__ frame_mask,
+                                                              float* __restrict__ out, float scale, float fill, int splits,
+                                                              int T_frames, int patches, int heads, int R) {
+  const int tpr = heads * 8;
+  const int b = blockIdx.y, split = blockIdx.x;
+  const int rs = threadIdx.x / tpr, tr = threadIdx.x % tpr;
+  const int hd = tr >> 3, sub = tr & 7;
+  const int S = T_frames * patches;
+  const int D = heads * HD;
+  const int per = (S + splits - 1) / splits;
+  const int s_begin = split * per;
+  const int s_end = min(S, s_begin + per);
+  float av[8];
+  {
+    const float* ap = a + ((int64_t)b * heads + hd) * a_stride + sub * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) av[e] = ap[e] * scale;
+  }
+  const T* xb = X + (int64_t)b * S * D + hd * HD + sub * 8;
+  for (int s = s_begin + rs; s < s_end; s += R) {
+    float xx[8];
+    Ld8<T>::load(xb + (int64_t)s * D, xx);
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d = fmaf(av[e], xx[e], d);
+    d = group8_sum(d);
+    if (sub == 0) {
+      const bool ok = frame_mask == nullptr || frame_mask[(int64_t)b * T_frames + s / patches] != 0;
+      out[((int64_t)b * heads + hd) * S + s] = ok ? d : fill;
+    }
+  }
+}
+
+// attn_mode (models.py:107-115): the softmax branch is a sum of grouped softmaxes over the scores
+// viewed [T, P]: "frame" normalises over the patches of each frame, "temporal" over the frames at
+// each patch position.  One block per (head, clip); scores and weights live in LDS.
+// A group whose keys are all padded gives NaN, as the reference's softmax over all -inf does.
+__global__ __launch_bounds__(256) void decoder_modes_fwd_kernel(const float* __restrict__ scores, float* __restrict__ weights,
+                                                                int modes, int T_frames, int patches) {
+  extern __shared__ float sm[];  // [S] scores | [S] weights
+  const int S = T_frames * patches;
+  float* sc = sm;
+  float* aw = sm + S;
+  const int64_t base = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * S;
+  for (int i = threadIdx.x; i < S; i += 256) { sc[i] = scores[base + i]; aw[i] = 0.f; }
+  __syncthreads();
+  if (modes & 1) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int t = wave; t < T_frames; t += 4) {
+      const float* row = sc + t * patches;
+      float m = -INFINITY;
+      for (int p = lane; p < patches; p += 64) m = fmaxf(m, row[p]);
+      m = wave_max(m);
+      float l = 0.f;
+      for (int p = lane; p < patches; p += 64) l += __expf(row[p] - m);
+      l = wave_sum(l);
+      for (int p = lane; p < patches; p += 64) aw[t * patches + p] += __expf(row[p] - m) / l;
+    }
+    __syncthreads();
+  }
+  if (modes & 2) {
+    for (int p = threadIdx.x; p < patches; p += 256) {
+      float m = -INFINITY;
+      for (int t = 0; t < T_frames; ++t) m = fmaxf(m, sc[t * patches + p]);
+      float l = 0.f;
+      for (int t = 0; t < T_frames; ++t) l += __expf(sc[t * patches + p] - m);
+      for (int t = 0; t < T_frames; ++t) aw[t * patches + p] += __expf(sc[t * patches + p] - m) / l;
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < S; i += 256) weights[base + i] = aw[i];
 }
 
 template <int EPI>
@@ -359,8 +448,9 @@ extern "C" size_t dfd_decoder_attn_workspace(int B, int heads, int d, int splits
 }
 
 extern "C" int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v, int kv_dtype,
-                                    const uint8_t* frame_mask, float* mix, float* mix_softmax, float* stats,
-                                    void* workspace, int splits, int B, int T, int patches, int heads, int d, void* stream) {
+                                    const uint8_t* frame_mask, const float* ext_weights, float* mix, float* mix_softmax,
+                                    float* stats, void* workspace, int splits, int B, int T, int patches, int heads, int d,
+                                    void* stream) {
   DFD_REQUIRE(q && k && v && frame_mask && mix && stats && workspace, "dfd_decoder_attn_fwd: null pointer");
   DFD_REQUIRE(d == HD, "dfd_decoder_attn_fwd: head dim %d, only 64 is supported", d);
   DFD_REQUIRE(B >= 0 && T > 0 && patches > 0 && heads > 0 && heads * HD <= 1024, "dfd_decoder_attn_fwd: bad shape");
@@ -377,13 +467,54 @@ extern "C" int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v
   float* ws = static_cast<float*>(workspace);
   if (kv_dtype == DFD_F32)
     hipLaunchKernelGGL((decoder_attn_partial_kernel<float>), grid, block, lds, st, q, static_cast<const float*>(k),
-                       static_cast<const float*>(v), frame_mask, ws, splits, T, patches, heads, R);
+                       static_cast<const float*>(v), frame_mask, ext_weights, ws, splits, T, patches, heads, R);
   else
     hipLaunchKernelGGL((decoder_attn_partial_kernel<bf16_t>), grid, block, lds, st, q, static_cast<const bf16_t*>(k),
-                       static_cast<const bf16_t*>(v), frame_mask, ws, splits, T, patches, heads, R);
+                       static_cast<const bf16_t*>(v), frame_mask, ext_weights, ws, splits, T, patches, heads, R);
   DFD_CHECK_LAUNCH("dfd_decoder_attn_fwd(partial)");
   hipLaunchKernelGGL(decoder_attn_combine_kernel, dim3(B), dim3(heads * HD), 0, st, ws, mix, mix_softmax, stats, splits, heads);
   DFD_CHECK_LAUNCH("dfd_decoder_attn_fwd(combine)");
+  return DFD_OK;
+}
+
+// shared by the attn_mode entry points (also used from decoder_bwd.hip through dfd_decoder_rowdot)
+int dfd_decoder_rowdot(const float* a, int a_stride, const void* X, int kv_dtype, const uint8_t* frame_mask, float* out,
+                       float scale, float fill, int B, int T, int patches, int heads, hipStream_t st) {
+  const int R = rows_per_block(heads);
+  const int threads = heads * 8 * R;
+  const int S = T * patches;
+  const int splits = max(1, min(S / 64, max(1, 768 / max(B, 1))));
+  const dim3 grid(splits, B), block(threads);
+  if (kv_dtype == DFD_F32)
+    hipLaunchKernelGGL((decoder_rowdot_kernel<float>), grid, block, 0, st, a, a_stride, static_cast<const float*>(X), frame_mask,
+                       out, scale, fill, splits, T, patches, heads, R);
+  else
+    hipLaunchKernelGGL((decoder_rowdot_kernel<bf16_t>), grid, block, 0, st, a, a_stride, static_cast<const bf16_t*>(X),
+                       frame_mask, out, scale, fill, splits, T, patches, heads, R);
+  DFD_CHECK_LAUNCH("dfd_decoder_rowdot");
+  return DFD_OK;
+}
+
+extern "C" int dfd_decoder_attn_modes_fwd(const float* q, const void* k, int kv_dtype, const uint8_t* frame_mask, int modes,
+                                          float* scores, float* weights, int B, int T, int patches, int heads, int d,
+                                          void* stream) {
+  DFD_REQUIRE(q && k && frame_mask && scores && weights, "dfd_decoder_attn_modes_fwd: null pointer");
+  DFD_REQUIRE(d == HD, "dfd_decoder_attn_modes_fwd: head dim %d, only 64 is supported", d);
+  DFD_REQUIRE(B >= 0 && T > 0 && patches > 0 && heads > 0 && heads * HD <= 1024, "dfd_decoder_attn_modes_fwd: bad shape");
+  DFD_REQUIRE(modes >= 1 && modes <= 3, "dfd_decoder_attn_modes_fwd: modes=%d (bit 0 frame, bit 1 temporal)", modes);
+  DFD_REQUIRE(kv_dtype == DFD_F32 || kv_dtype == DFD_BF16, "dfd_decoder_attn_modes_fwd: kv_dtype=%d", kv_dtype);
+  DFD_REQUIRE(dfd_aligned16(k) && dfd_aligned16(q), "dfd_decoder_attn_modes_fwd: pointers must be 16-byte aligned");
+  const size_t lds = (size_t)2 * T * patches * sizeof(float);
+  DFD_REQUIRE(lds <= 150 * 1024, "dfd_decoder_attn_modes_fwd: T*patches=%d too large for one LDS pass", T * patches);
+  if (B == 0) return DFD_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // softmax-branch scores q_s·k/√d, -inf on padded frames (models.py:103-104); q holds [softmax | CoDA] per head
+  const int rc = dfd_decoder_rowdot(q, 2 * HD, k, kv_dtype, frame_mask, scores, 0.125f, -INFINITY, B, T, patches, heads, st);
+  if (rc != DFD_OK) return rc;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decoder_modes_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(decoder_modes_fwd_kernel, dim3(heads, B), dim3(256), lds, st, scores, weights, modes, T, patches);
+  DFD_CHECK_LAUNCH("dfd_decoder_attn_modes_fwd");
   return DFD_OK;
 }
 

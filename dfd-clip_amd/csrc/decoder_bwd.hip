@@ -47,7 +47,9 @@ __global__ __launch_bounds__(1024) void decoder_attn_bwd_kernel(const float* __r
                                                                 const uint8_t* __restrict__ frame_mask,
                                                                 const float* __restrict__ dmix,
                                                                 const float* __restrict__ mix_s,
-                                                                const float* __restrict__ stats, float* __restrict__ part,
+                                                                const float* __restrict__ stats,
+                                                                const float* __restrict__ ext_w,
+                                                                const float* __restrict__ ext_ds, float* __restrict__ part,
                                                                 G* __restrict__ dk_out, G* __restrict__ dv_out,
                                                                 int T_frames, int patches, int heads, int R) {
   extern __shared__ float red[];  // [R][tpr][24]
@@ -74,15 +76,17 @@ __global__ __launch_bounds__(1024) void decoder_attn_bwd_kernel(const float* __r
     }
   }
   // Σ_i a_i·(dmix·v_i)/2 = (dmix · mix_softmax)/2
-  float dlt = 0.f;
-  {
+  // attn_mode: softmax-branch weights and score gradients come from the grouped-softmax passes (ext_*)
+  const bool ext = ext_w != nullptr;
+  float dlt = 0.f, M = 0.f, invL = 1.f;
+  if (!ext) {
     const float* mp = mix_s + (int64_t)b * D + hd * HD + sub * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) dlt = fmaf(dm[e], mp[e], dlt);
     dlt = 0.5f * group8_sum(dlt);
+    M = stats[((int64_t)b * heads + hd) * 2];
+    invL = 1.0f / stats[((int64_t)b * heads + hd) * 2 + 1];
   }
-  const float M = stats[((int64_t)b * heads + hd) * 2], Lsum = stats[((int64_t)b * heads + hd) * 2 + 1];
-  const float invL = 1.0f / Lsum;
 
   if (valid) {
     const int s0 = t * patches;
@@ -104,12 +108,13 @@ __global__ __launch_bounds__(1024) void decoder_attn_bwd_kernel(const float* __r
       tt = group8_sum(tt);
       l1 = group8_sum(l1);
       dw = group8_sum(dw);
-      const float aw = __expf(s - M) * invL;                       // softmax weight
+      const int64_t wi = ((int64_t)b * heads + hd) * S + s0 + j;
+      const float aw = ext ? ext_w[wi] : __expf(s - M) * invL;      // softmax(-branch) weight
       const float g = 2.0f / (1.0f + __expf(l1 * 0.125f));         // 2·sigmoid(−l1/8)
       const float e2 = __expf(2.0f * tt);
       const float th = 1.0f - 2.0f / (e2 + 1.0f);                  // tanh
       const float w = 0.5f * (aw + th * g);
-      const float ds = aw * (0.5f * dw - dlt);
+      const float ds = ext ? ext_ds[wi] : aw * (0.5f * dw - dlt);
       const float dc = 0.5f * dw;
       const float dt = dc * g * (1.0f - th * th);
       const float dL = -(dc * th) * g * (1.0f - 0.5f * g) * 0.125f;
@@ -165,6 +170,62 @@ __global__ __launch_bounds__(1024) void decoder_attn_bwd_kernel(const float* __r
       dst[2 * D + hd * HD + sub * 8 + e] = acc[16 + e];
     }
   }
+}
+
+// Backward of decoder_modes_fwd_kernel: with p the grouped-softmax weights of one mode and
+// dp = dmix·v/2 (the branch average), ds = Σ_modes p·(dp − Σ_group p·dp).
+__global__ __launch_bounds__(256) void decoder_modes_bwd_kernel(const float* __restrict__ scores, const float* __restrict__ dwv,
+                                                                float* __restrict__ dscores, int modes, int T_frames,
+                                                                int patches) {
+  extern __shared__ float sm[];  // [S] scores | [S] dp | [S] ds
+  const int S = T_frames * patches;
+  float* sc = sm;
+  float* dp = sm + S;
+  float* ds = sm + 2 * S;
+  const int64_t base = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * S;
+  for (int i = threadIdx.x; i < S; i += 256) { sc[i] = scores[base + i]; dp[i] = 0.5f * dwv[base + i]; ds[i] = 0.f; }
+  __syncthreads();
+  if (modes & 1) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int t = wave; t < T_frames; t += 4) {
+      const float* row = sc + t * patches;
+      const float* dr = dp + t * patches;
+      float m = -INFINITY;
+      for (int p = lane; p < patches; p += 64) m = fmaxf(m, row[p]);
+      m = wave_max(m);
+      float l = 0.f, dd = 0.f;
+      for (int p = lane; p < patches; p += 64) {
+        const float e = __expf(row[p] - m);
+        l += e;
+        dd = fmaf(e, dr[p], dd);
+      }
+      l = wave_sum(l);
+      dd = wave_sum(dd) / l;
+      for (int p = lane; p < patches; p += 64) ds[t * patches + p] += __expf(row[p] - m) / l * (dr[p] - dd);
+    }
+    __syncthreads();
+  }
+  if (modes & 2) {
+    for (int p = threadIdx.x; p < patches; p += 256) {
+      float m = -INFINITY;
+      for (int t = 0; t < T_frames; ++t) m = fmaxf(m, sc[t * patches + p]);
+      float l = 0.f, dd = 0.f;
+      for (int t = 0; t < T_frames; ++t) {
+        const float e = __expf(sc[t * patches + p] - m);
+        l += e;
+        dd = fmaf(e, dp[t * patches + p], dd);
+      }
+      dd /= l;
+      for (int t = 0; t < T_frames; ++t) {
+        const int i = t * patches + p;
+        // a padded frame has weight exactly 0; keep its gradient 0 rather than 0·(dp − D)
+        const float w = __expf(sc[i] - m) / l;
+        ds[i] += (w == 0.f) ? 0.f : w * (dp[i] - dd);
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < S; i += 256) dscores[base + i] = ds[i];
 }
 
 // dq[b, :] = Σ_t part[b, t, 0:2D];  dpos[t, :] = Σ_b part[b, t, 2D:3D]
@@ -345,10 +406,13 @@ extern "C" size_t dfd_decoder_attn_bwd_workspace(int B, int T, int heads, int d)
 }
 
 extern "C" int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v, int kv_dtype, const uint8_t* frame_mask,
-                                    const float* dmix, const float* mix_softmax, const float* stats, float* dq, float* dpos,
-                                    void* dk, void* dv, int dkv_dtype, void* workspace, int B, int T, int patches, int heads,
-                                    int d, void* stream) {
-  DFD_REQUIRE(q && k && v && frame_mask && dmix && mix_softmax && stats && dq && workspace, "dfd_decoder_attn_bwd: null pointer");
+                                    const float* dmix, const float* mix_softmax, const float* stats,
+                                    const float* ext_weights, const float* ext_dscores, float* dq, float* dpos, void* dk,
+                                    void* dv, int dkv_dtype, void* workspace, int B, int T, int patches, int heads, int d,
+                                    void* stream) {
+  DFD_REQUIRE(q && k && v && frame_mask && dmix && dq && workspace, "dfd_decoder_attn_bwd: null pointer");
+  DFD_REQUIRE(!ext_weights == !ext_dscores, "dfd_decoder_attn_bwd: ext_weights and ext_dscores go together");
+  DFD_REQUIRE(ext_weights || (mix_softmax && stats), "dfd_decoder_attn_bwd: mix_softmax and stats are required without ext_weights");
   DFD_REQUIRE(d == HD, "dfd_decoder_attn_bwd: head dim %d, only 64 is supported", d);
   DFD_REQUIRE(B >= 0 && T > 0 && patches > 0 && heads > 0 && heads * HD <= 1024, "dfd_decoder_attn_bwd: bad shape");
   DFD_REQUIRE(kv_dtype == DFD_F32 || kv_dtype == DFD_BF16, "dfd_decoder_attn_bwd: kv_dtype=%d", kv_dtype);
@@ -369,7 +433,8 @@ extern "C" int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decoder_attn_bwd_kernel<KT, GT>),                             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
     hipLaunchKernelGGL((decoder_attn_bwd_kernel<KT, GT>), grid, block, lds, st, q, static_cast<const KT*>(k),                  \
-                       static_cast<const KT*>(v), frame_mask, dmix, mix_softmax, stats, part, static_cast<GT*>(dk),           \
+                       static_cast<const KT*>(v), frame_mask, dmix, mix_softmax, stats, ext_weights, ext_dscores, part,      \
+                       static_cast<GT*>(dk),                                                                                  \
                        static_cast<GT*>(dv), T, patches, heads, R);                                                         \
   } while (0)
   const bool gb = dk && dkv_dtype == DFD_BF16;
@@ -380,6 +445,32 @@ extern "C" int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v
   const int total = B * 2 * D + (dpos ? T * D : 0);
   hipLaunchKernelGGL(decoder_attn_bwd_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, dq, dpos, B, T, D);
   DFD_CHECK_LAUNCH("dfd_decoder_attn_bwd(reduce)");
+  return DFD_OK;
+}
+
+int dfd_decoder_rowdot(const float* a, int a_stride, const void* X, int kv_dtype, const uint8_t* frame_mask, float* out,
+                       float scale, float fill, int B, int T, int patches, int heads, hipStream_t st);  // decoder.hip
+
+extern "C" int dfd_decoder_attn_modes_bwd(const float* scores, const void* v, int kv_dtype, const float* dmix, int modes,
+                                          float* dwv_workspace, float* dscores, int B, int T, int patches, int heads, int d,
+                                          void* stream) {
+  DFD_REQUIRE(scores && v && dmix && dwv_workspace && dscores, "dfd_decoder_attn_modes_bwd: null pointer");
+  DFD_REQUIRE(d == HD, "dfd_decoder_attn_modes_bwd: head dim %d, only 64 is supported", d);
+  DFD_REQUIRE(B >= 0 && T > 0 && patches > 0 && heads > 0 && heads * HD <= 1024, "dfd_decoder_attn_modes_bwd: bad shape");
+  DFD_REQUIRE(modes >= 1 && modes <= 3, "dfd_decoder_attn_modes_bwd: modes=%d (bit 0 frame, bit 1 temporal)", modes);
+  DFD_REQUIRE(kv_dtype == DFD_F32 || kv_dtype == DFD_BF16, "dfd_decoder_attn_modes_bwd: kv_dtype=%d", kv_dtype);
+  DFD_REQUIRE(dfd_aligned16(v) && dfd_aligned16(dmix), "dfd_decoder_attn_modes_bwd: pointers must be 16-byte aligned");
+  const size_t lds = (size_t)3 * T * patches * sizeof(float);
+  DFD_REQUIRE(lds <= 150 * 1024, "dfd_decoder_attn_modes_bwd: T*patches=%d too large for one LDS pass", T * patches);
+  if (B == 0) return DFD_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // dL/d(weight of key s) = dmix · v_s  (weights multiply v in the mix, models.py:144)
+  const int rc = dfd_decoder_rowdot(dmix, HD, v, kv_dtype, nullptr, dwv_workspace, 1.0f, 0.f, B, T, patches, heads, st);
+  if (rc != DFD_OK) return rc;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decoder_modes_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(decoder_modes_bwd_kernel, dim3(heads, B), dim3(256), lds, st, scores, dwv_workspace, dscores, modes, T, patches);
+  DFD_CHECK_LAUNCH("dfd_decoder_attn_modes_bwd");
   return DFD_OK;
 }
 

@@ -62,20 +62,25 @@ class Decoder(nn.Module):
             self.positional_embedding = nn.Parameter(scale * torch.randn(num_frames, 1, heads, width // heads))
         else:
             self.positional_embedding = None
+        # attn_mode "frame", "temporal" or "frame+temporal": grouped softmaxes in the softmax branch (models.py:97, :107-115)
+        self.attn_modes = 0
         if "attn_mode" in config.op_mode and config.op_mode.attn_mode:
-            raise NotImplementedError("op_mode.attn_mode (frame/temporal softmax factorisation) is not built yet")
+            for name in config.op_mode.attn_mode.split("+"):
+                self.attn_modes |= capi.ATTN_MODE_BITS.get(name, 0)  # unknown names add nothing, as in the reference
+            if self.attn_modes == 0:
+                raise ValueError(f"op_mode.attn_mode={config.op_mode.attn_mode!r}: the reference sums an empty list here")
         self.global_prediction = bool("global_prediction" in config.op_mode and config.op_mode.global_prediction)
-        if self.global_prediction:
-            raise NotImplementedError("op_mode.global_prediction is not built yet")
         self.ln_pre = nn.LayerNorm(width)
         self.transformer = DecoderTransformer(width, len(self.layer_indices),
                                               bool("aug_query" in config.op_mode and config.op_mode.aug_query))
         self.ln_post = nn.LayerNorm(width)
         self.task_projections = []
         for i, od in enumerate(self.out_dims):
-            name = f"proj{i}x{od}"
-            setattr(self, name, nn.Parameter(scale * torch.randn(width, od)))
-            self.task_projections.append([getattr(self, name)])
+            # one projection per task, or one per tapped layer with `global_prediction` (models.py:306-321)
+            names = [f"proj{i}x{od}_L{l}" for l in self.layer_indices] if self.global_prediction else [f"proj{i}x{od}"]
+            for name in names:
+                setattr(self, name, nn.Parameter(scale * torch.randn(width, od)))
+            self.task_projections.append([getattr(self, name) for name in names])
         self._wt_cache = {}  # name -> (parameter version, transposed f32 copy) for the row-streaming linear kernel
         # decoder blocks start from the encoder layer they read (models.py:226-229)
         for b, l in enumerate(self.layer_indices):
@@ -182,6 +187,8 @@ class Decoder(nn.Module):
         x = new(B, D)
         capi.layernorm(x0, g("ln_pre.weight"), g("ln_pre.bias"), x)
         saved = dict(x0=x0, blocks=[])
+        xs = []  # per-block outputs, read by the per-layer heads of `global_prediction`
+        mode_ws = None
         h, q, mix, stats, u = new(B, D), new(B, 2 * D), new(B, D), new(B, H, 2), new(B, 4 * D)
         for i in range(L):
             pre = f"transformer.resblocks.{i}."
@@ -190,7 +197,12 @@ class Decoder(nn.Module):
                 x_in = x
                 capi.layernorm(x_in, g(pre + "ln_1.weight"), g(pre + "ln_1.bias"), h1)
                 lin(h1, pre + "attn.in_proj.", q)
-                capi.decoder_attn_fwd(q, k_all[i], v_all[i], mask, mix, stats, ws, splits, B, T, P, H, mix_softmax=mix_s)
+                sc = aw = None
+                if self.attn_modes:
+                    sc, aw = new(B, H, T * P), new(B, H, T * P)
+                    capi.decoder_attn_modes_fwd(q, k_all[i], mask, self.attn_modes, sc, aw, B, T, P, H)
+                capi.decoder_attn_fwd(q, k_all[i], v_all[i], mask, mix, stats, ws, splits, B, T, P, H, mix_softmax=mix_s,
+                                      ext_weights=aw)
                 x_mid = x_in.clone()
                 lin(mix, pre + "attn.out_proj.", x_mid, capi.EPI_BIAS_RESIDUAL)
                 h2, u_pre, uu = new(B, D), new(B, 4 * D), new(B, 4 * D)
@@ -200,27 +212,50 @@ class Decoder(nn.Module):
                 x = x_mid.clone()
                 lin(uu, pre + "mlp.c_proj.", x, capi.EPI_BIAS_RESIDUAL)
                 saved["blocks"].append(dict(x_in=x_in, h1=h1, q=q, mix=mix, mix_s=mix_s, stats=stats, x_mid=x_mid, h2=h2,
-                                            u_pre=u_pre, u=uu))
+                                            u_pre=u_pre, u=uu, sc=sc, aw=aw))
             else:
                 capi.layernorm(x, g(pre + "ln_1.weight"), g(pre + "ln_1.bias"), h)
                 lin(h, pre + "attn.in_proj.", q)
-                capi.decoder_attn_fwd(q, k_all[i], v_all[i], mask, mix, stats, ws, splits, B, T, P, H)
+                aw = None
+                if self.attn_modes:
+                    if mode_ws is None:
+                        mode_ws = (new(B, H, T * P), new(B, H, T * P))
+                    aw = capi.decoder_attn_modes_fwd(q, k_all[i], mask, self.attn_modes, mode_ws[0], mode_ws[1], B, T, P, H)
+                capi.decoder_attn_fwd(q, k_all[i], v_all[i], mask, mix, stats, ws, splits, B, T, P, H, ext_weights=aw)
                 lin(mix, pre + "attn.out_proj.", x, capi.EPI_BIAS_RESIDUAL)
                 capi.layernorm(x, g(pre + "ln_2.weight"), g(pre + "ln_2.bias"), h)
                 lin(h, pre + "mlp.c_fc.", u, capi.EPI_BIAS_QUICKGELU)
                 lin(u, pre + "mlp.c_proj.", x, capi.EPI_BIAS_RESIDUAL)
+            if self.global_prediction:
+                xs.append(x if save else x.clone())
             aq = f"transformer.augment_query_{i}"
             if aq in w and i != L - 1:
                 # result.append(x) precedes the add in the reference (models.py:263-267); only the last
                 # block's x is read when there is one projection per task (models.py:340-341)
                 x = x + g(aq)
-        feat = new(B, D)
         raws, outs = [], []
-        for i, od in enumerate(self.out_dims):
-            raw, logits = new(B, od), new(B, od)
-            capi.head_fwd(x, g("ln_post.weight"), g("ln_post.bias"), g(f"proj{i}x{od}"), feat, raw, logits)
-            raws.append(raw)
-            outs.append(logits)
+        if self.global_prediction:
+            # every block's output goes through ln_post and its own projection; the logits are the
+            # (j+1)/(L(L+1)/2)-weighted sum (models.py:345-357).  video_feature is [B, L, D].
+            feat = new(B, L, D)
+            cw = [(j + 1) / ((1 + L) * L / 2) for j in range(L)]
+            for i, od in enumerate(self.out_dims):
+                z = torch.zeros(B, od, **f32)
+                for j, l in enumerate(self.layer_indices):
+                    fj, rj, tmp = new(B, D), new(B, od), new(B, od)
+                    capi.head_fwd(xs[j], g("ln_post.weight"), g("ln_post.bias"), g(f"proj{i}x{od}_L{l}"), fj, rj, tmp)
+                    feat[:, j] = fj
+                    z += cw[j] * rj
+                raws.append(z)
+                outs.append(5.0 * z / (z.norm(dim=-1, keepdim=True) + 1e-10))  # models.py:551-553
+            saved["xs"] = xs
+        else:
+            feat = new(B, D)
+            for i, od in enumerate(self.out_dims):
+                raw, logits = new(B, od), new(B, od)
+                capi.head_fwd(x, g("ln_post.weight"), g("ln_post.bias"), g(f"proj{i}x{od}"), feat, raw, logits)
+                raws.append(raw)
+                outs.append(logits)
         saved["x_last"] = x
         saved["feat"] = feat
         saved["raws"] = raws
@@ -255,30 +290,61 @@ class Decoder(nn.Module):
 
         # ---- head: logits = 5 z/(|z|+eps), z = feat @ proj, feat = ln_post(x_last)
         feat, x_last = saved["feat"], saved["x_last"]
-        dfeat = d_feat.contiguous().clone() if d_feat is not None else None
-        for i, od in enumerate(self.out_dims):
-            raw = saved["raws"][i]
-            proj = g(f"proj{i}x{od}")
-            dz, dfi, dproj = new(B, od), new(B, D), new(D, od)
-            dl = d_logits[i]
-            if dl is None:  # gradient only through the raw (un-normalised) logits, or none at all
-                dz = d_raws[i].contiguous() if d_raws[i] is not None else torch.zeros(B, od, **f32)
-                capi.head_bwd(raw, torch.zeros(B, od, **f32), proj, feat, dfeat, new(B, od), dfi, dproj)
-                dproj = feat.t().contiguous() @ dz  # rare path (raw logits consumed directly): plain glue
-                dfi = dfi + dz @ proj.t()
-            else:
-                capi.head_bwd(raw, dl.contiguous(), proj, feat, dfeat, dz, dfi, dproj)
-                if d_raws[i] is not None:
-                    dproj = dproj + feat.t().contiguous() @ d_raws[i]
-                    dfi = dfi + d_raws[i] @ proj.t()
-            grads[f"proj{i}x{od}"] = dproj
-            dfeat = dfi
-        if dfeat is None:
-            dfeat = torch.zeros(B, D, **f32)
-        dx = new(B, D)
-        dgam, dbet = new(D), new(D)
-        capi.layernorm_bwd(x_last, g("ln_post.weight"), dfeat, dx, dgam, dbet, xhat)
-        grads["ln_post.weight"], grads["ln_post.bias"] = dgam, dbet
+        head_dx = None  # global_prediction: gradient entering each block's output from its own head
+        if self.global_prediction:
+            # z = Σ_j c_j feat_j @ proj_j.  head_bwd is linear in dlogits, so calling it with c_j·dlogits on the
+            # summed z yields dz_j = c_j dz, dproj_j = feat_jᵀ dz_j and dfeat_j = dz_j proj_jᵀ (+ external dfeat_j)
+            cw = [(j + 1) / ((1 + L) * L / 2) for j in range(L)]
+            dfeat_layers = [d_feat[:, j].contiguous().clone() if d_feat is not None else None for j in range(L)]
+            for i, od in enumerate(self.out_dims):
+                z = saved["raws"][i]
+                dl = d_logits[i].contiguous() if d_logits[i] is not None else torch.zeros(B, od, **f32)
+                for j, l in enumerate(self.layer_indices):
+                    name = f"proj{i}x{od}_L{l}"
+                    proj, fj = g(name), feat[:, j].contiguous()
+                    dz, dfj, dproj = new(B, od), new(B, D), new(D, od)
+                    capi.head_bwd(z, cw[j] * dl, proj, fj, dfeat_layers[j], dz, dfj, dproj)
+                    if d_raws[i] is not None:  # raw logits consumed directly (rare): plain glue
+                        dproj = dproj + fj.t().contiguous() @ (cw[j] * d_raws[i])
+                        dfj = dfj + (cw[j] * d_raws[i]) @ proj.t()
+                    grads[name] = dproj
+                    dfeat_layers[j] = dfj
+            head_dx = []
+            dgam_t, dbet_t = torch.zeros(D, **f32), torch.zeros(D, **f32)
+            for j in range(L):
+                dxj, dgam, dbet = new(B, D), new(D), new(D)
+                dfj = dfeat_layers[j] if dfeat_layers[j] is not None else torch.zeros(B, D, **f32)
+                capi.layernorm_bwd(saved["xs"][j], g("ln_post.weight"), dfj, dxj, dgam, dbet, xhat)
+                head_dx.append(dxj)
+                dgam_t += dgam
+                dbet_t += dbet
+            grads["ln_post.weight"], grads["ln_post.bias"] = dgam_t, dbet_t
+            dx = head_dx[L - 1]
+        else:
+            dfeat = d_feat.contiguous().clone() if d_feat is not None else None
+            for i, od in enumerate(self.out_dims):
+                raw = saved["raws"][i]
+                proj = g(f"proj{i}x{od}")
+                dz, dfi, dproj = new(B, od), new(B, D), new(D, od)
+                dl = d_logits[i]
+                if dl is None:  # gradient only through the raw (un-normalised) logits, or none at all
+                    dz = d_raws[i].contiguous() if d_raws[i] is not None else torch.zeros(B, od, **f32)
+                    capi.head_bwd(raw, torch.zeros(B, od, **f32), proj, feat, dfeat, new(B, od), dfi, dproj)
+                    dproj = feat.t().contiguous() @ dz  # rare path (raw logits consumed directly): plain glue
+                    dfi = dfi + dz @ proj.t()
+                else:
+                    capi.head_bwd(raw, dl.contiguous(), proj, feat, dfeat, dz, dfi, dproj)
+                    if d_raws[i] is not None:
+                        dproj = dproj + feat.t().contiguous() @ d_raws[i]
+                        dfi = dfi + d_raws[i] @ proj.t()
+                grads[f"proj{i}x{od}"] = dproj
+                dfeat = dfi
+            if dfeat is None:
+                dfeat = torch.zeros(B, D, **f32)
+            dx = new(B, D)
+            dgam, dbet = new(D), new(D)
+            capi.layernorm_bwd(x_last, g("ln_post.weight"), dfeat, dx, dgam, dbet, xhat)
+            grads["ln_post.weight"], grads["ln_post.bias"] = dgam, dbet
 
         ws = new(capi.decoder_attn_bwd_workspace_bytes(B, T, H) // 4)
         has_pos = "positional_embedding" in w
@@ -291,6 +357,8 @@ class Decoder(nn.Module):
             aq = f"transformer.augment_query_{i}"
             if aq in w and i != L - 1:
                 grads[aq] = dx.sum(dim=0)  # x_{i+1,in} = x_{i,out} + aq_i
+            if head_dx is not None and i != L - 1:
+                dx = dx + head_dx[i]  # block i's output also feeds its own head
             # x_out = x_mid + c_proj(u)
             du = lin_bwd(pre + "mlp.c_proj.", dx, sv["u"])
             du_pre = new(B, 4 * D)
@@ -303,8 +371,13 @@ class Decoder(nn.Module):
             dmix = lin_bwd(pre + "attn.out_proj.", dx, sv["mix"])
             dq = new(B, 2 * D)
             dpos = new(T, D) if has_pos else None
+            dsc = None
+            if self.attn_modes:
+                dsc = new(B, H, T * P)
+                capi.decoder_attn_modes_bwd(sv["sc"], v_all[i], dmix, self.attn_modes, new(B, H, T * P), dsc, B, T, P, H)
             capi.decoder_attn_bwd(sv["q"], k_all[i], v_all[i], mask, dmix, sv["mix_s"], sv["stats"], dq, dpos, ws, B, T, P, H,
-                                  dk=dk_all[i] if want_dkv else None, dv=dv_all[i] if want_dkv else None)
+                                  dk=dk_all[i] if want_dkv else None, dv=dv_all[i] if want_dkv else None,
+                                  ext_weights=sv["aw"], ext_dscores=dsc)
             if has_pos:
                 dpos_total += dpos
             dh1 = lin_bwd(pre + "attn.in_proj.", dq, sv["h1"])

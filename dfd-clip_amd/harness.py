@@ -9,6 +9,9 @@ code, so that a reference user finds the same step semantics on top of `Detector
   make_one_cycle  the OneCycleLR the trainer builds (`src/trainer.py:51-60`): initial lr = max/25 and
                   `total_steps = max_steps * num_processes` because Accelerate steps a prepared
                   scheduler once per process per optimizer step; `step_scheduler` mirrors that.
+  EmaTeacher      the trainer's "teacher" mode (`src/trainer.py:66-69`, `:124-137`, `:179-190`): a deep copy of
+                  the model updated as an exponential moving average after every optimizer step; once
+                  `teach_at` steps have passed it supplies soft labels for the tasks a batch has no labels for.
   evaluate        `Evaluator.run` (`src/evaluator.py:50-97`) + the metric callbacks
                   (`src/callbacks/metrics.py:86-155`): no_grad, eval(), model(x, y_list, m, single_task)
                   -> softmax -> gather over ranks -> accuracy / AUROC on p[:, 1].
@@ -16,6 +19,8 @@ code, so that a reference user finds the same step semantics on top of `Detector
                   clip- or video-level (mean over clips) probabilities -> gather -> accuracy / AUROC with
                   the dummy [0, 1] pair the reference appends before computing.
 """
+import copy
+
 import torch
 from torch.optim.lr_scheduler import OneCycleLR
 
@@ -32,18 +37,57 @@ def step_scheduler(scheduler, num_processes=None):
         scheduler.step()
 
 
-def train_step(model, optimizer, batches, scheduler=None, total_tasks=None):
+class EmaTeacher:
+    """EMA copy of the model that labels the tasks a batch does not cover (reference
+    `src/trainer.py:66-69` deep copy, `:179-185` update p_t <- (1-r) p_t + r p, `:188-190` teaching
+    starts once `teach_at < steps`, `:124-137` pseudo labels = softmax of the teacher's logits)."""
+
+    def __init__(self, model, ema_ratio, teach_at):
+        self.module = copy.deepcopy(model)
+        self.ema_ratio = float(ema_ratio)
+        self.teach_at = int(teach_at)
+        self.steps = 0
+        self.teaching = False
+
+    @torch.no_grad()
+    def update(self, model):
+        r = self.ema_ratio
+        for p1, p2 in zip(self.module.parameters(), model.parameters()):
+            p1.data = (1 - r) * p1.data + r * p2.data
+        self.steps += 1
+        if not self.teaching and self.teach_at < self.steps:
+            self.teaching = True
+
+    @torch.no_grad()
+    def labels(self, frames, mask, labels, task_index, total_tasks):
+        """Per-task label list: the batch's own labels for its task, the teacher's class probabilities
+        for every other task (the model's losses accept probability targets)."""
+        _, teacher_logits = self.module(frames, [None] * total_tasks, mask, single_task=-1)
+        return [labels if i == task_index else teacher_logits[i].softmax(dim=-1) for i in range(total_tasks)]
+
+
+def train_step(model, optimizer, batches, scheduler=None, total_tasks=None, teacher=None):
     """One optimizer step over `batches`: list of (frames, labels, mask, comps, speed, task_index)
     — one entry per training set, as the reference draws one batch per set per step.
+    With an `EmaTeacher` that has started teaching, every task contributes a loss (the other tasks
+    against the teacher's soft labels); the teacher is updated after the optimizer step.
     Returns {"losses": [...per batch mean task loss...], "logits": [...]}."""
     total_tasks = total_tasks or len(model.out_dim)
     model.zero_grad()
     model.train()
     out = {"losses": [], "logits": []}
+    teaching = teacher is not None and teacher.teaching
     for frames, labels, mask, comps, speed, task_index in batches:
-        y_list = [labels if i == task_index else None for i in range(total_tasks)]
-        task_losses, task_logits, other = model(frames, y_list, mask, comps, speed, train=True, single_task=task_index)
-        loss = task_losses[task_index].mean() + sum(other[k].mean() for k in other)
+        if teaching:
+            y_list = teacher.labels(frames, mask, labels, task_index, total_tasks)
+        else:
+            y_list = [labels if i == task_index else None for i in range(total_tasks)]
+        task_losses, task_logits, other = model(frames, y_list, mask, comps, speed, train=True,
+                                                single_task=None if teaching else task_index)
+        if teaching:
+            loss = sum(l.mean() for l in task_losses) + sum(other[k].mean() for k in other)
+        else:
+            loss = task_losses[task_index].mean() + sum(other[k].mean() for k in other)
         loss.backward()
         out["losses"].append(task_losses[task_index].detach())
         out["logits"].append(task_logits[task_index].detach())
@@ -52,6 +96,8 @@ def train_step(model, optimizer, batches, scheduler=None, total_tasks=None):
     if scheduler is not None:
         step_scheduler(scheduler)
     model.zero_grad()
+    if teacher is not None:
+        teacher.update(model)
     return out
 
 

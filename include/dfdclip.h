@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DFD_ABI_VERSION 4
+#define DFD_ABI_VERSION 5
 
 enum { DFD_F32 = 0, DFD_BF16 = 1 };
 
@@ -134,14 +134,24 @@ int dfd_linear_rows_t(const float* x, int64_t ldx, const float* Wt, const float*
  *   q          f32 [B, heads, 2*d]  (in_proj output: per head softmax query then CoDA query)
  *   k, v       kv_dtype [B, S, heads*d]
  *   frame_mask u8 [B, T], S == T * patches
+ *   ext_weights f32 [B, heads, S] or NULL: softmax-branch weights computed elsewhere (attn_mode, below)
  *   mix        f32 [B, heads*d]
  *   mix_softmax f32 [B, heads*d] or NULL: the softmax branch alone (Σ a_j v_j), kept for backward
  *   stats      f32 [B, heads, 2] = (row max, sum of exp) of the softmax branch, kept for backward
  *   workspace  f32, at least dfd_decoder_attn_workspace(B, heads, d, splits) bytes. */
 size_t dfd_decoder_attn_workspace(int B, int heads, int d, int splits);
 int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v, int kv_dtype, const uint8_t* frame_mask,
-                         float* mix, float* mix_softmax, float* stats, void* workspace, int splits, int B, int T,
-                         int patches, int heads, int d, void* stream);
+                         const float* ext_weights, float* mix, float* mix_softmax, float* stats, void* workspace,
+                         int splits, int B, int T, int patches, int heads, int d, void* stream);
+
+/* op_mode.attn_mode (models.py:107-115): the softmax branch becomes a sum of grouped softmaxes of the
+ * scores viewed [T, patches] — bit 0 of `modes` = "frame" (over the patches of each frame), bit 1 =
+ * "temporal" (over the frames at each patch position).  Writes scores [B, heads, S] = q_s·k/√d (-inf on
+ * padded frames) and weights [B, heads, S] = Σ_modes softmax_mode(scores); pass `weights` to
+ * dfd_decoder_attn_fwd as ext_weights (mix_softmax / stats are then not meaningful).  A group with
+ * every key padded yields NaN, as in the reference. */
+int dfd_decoder_attn_modes_fwd(const float* q, const void* k, int kv_dtype, const uint8_t* frame_mask, int modes,
+                               float* scores, float* weights, int B, int T, int patches, int heads, int d, void* stream);
 
 /* Head: video_feature = LayerNorm(x) (ln_post), z = video_feature @ proj [D, out_dim],
  * logits = 5 z / (‖z‖₂ + 1e-10)  (models.py:342-343, :359, :551-553).  All f32. */
@@ -174,9 +184,16 @@ int dfd_adapter_norm_gelu_bwd(const void* a, const void* dy, void* da, int dtype
  *   workspace >= dfd_decoder_attn_bwd_workspace(B, T, heads, d) bytes. */
 size_t dfd_decoder_attn_bwd_workspace(int B, int T, int heads, int d);
 int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v, int kv_dtype, const uint8_t* frame_mask,
-                         const float* dmix, const float* mix_softmax, const float* stats, float* dq, float* dpos,
-                         void* dk, void* dv, int dkv_dtype, void* workspace, int B, int T, int patches, int heads,
-                         int d, void* stream);
+                         const float* dmix, const float* mix_softmax, const float* stats, const float* ext_weights,
+                         const float* ext_dscores, float* dq, float* dpos, void* dk, void* dv, int dkv_dtype,
+                         void* workspace, int B, int T, int patches, int heads, int d, void* stream);
+
+/* attn_mode backward, first half: from the forward's scores and dmix, dscores [B, heads, S] = dL/d(scores)
+ * through the grouped softmaxes.  dwv_workspace: f32 [B, heads, S].  Then call dfd_decoder_attn_bwd with
+ * ext_weights = the forward's weights and ext_dscores = dscores (mix_softmax / stats may be NULL). */
+int dfd_decoder_attn_modes_bwd(const float* scores, const void* v, int kv_dtype, const float* dmix, int modes,
+                               float* dwv_workspace, float* dscores, int B, int T, int patches, int heads, int d,
+                               void* stream);
 
 /* dW[N,K] = dyᵀ x, db[N] = Σ_b dy (db may be NULL): weight gradient of dfd_linear_rows. */
 int dfd_linear_rows_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dW, float* db, int B,

@@ -73,6 +73,60 @@ def test_decoder_attention_backward(capi, B, T, P, heads, dtype):
     assert torch.equal(dq, dq2) and torch.equal(dpos, dpos2)
 
 
+@pytest.mark.parametrize("modes", ["frame", "temporal", "frame+temporal"])
+@pytest.mark.parametrize("B,T,P,heads,dtype", [(2, 4, 4, 2, torch.float32), (3, 5, 196, 4, torch.bfloat16),
+                                               (2, 30, 196, 12, torch.bfloat16), (2, 8, 256, 16, torch.float32)])
+def test_decoder_attention_modes(capi, modes, B, T, P, heads, dtype):
+    """op_mode.attn_mode (reference src/models.py:107-115): grouped softmaxes in the softmax branch,
+    forward and backward against autograd of the oracle.  "temporal" also runs with padded frames
+    (weight 0); "frame" would be NaN there, in the reference as well, so it gets full clips."""
+    D, S = heads * 64, T * P
+    attn_mode = tuple(modes.split("+"))
+    bits = sum(capi.ATTN_MODE_BITS[a] for a in attn_mode)
+    k = rnd(B, S, heads, 64, seed=1).to(dtype).float()
+    v = rnd(B, S, heads, 64, seed=2).to(dtype).float()
+    q = rnd(B, 1, heads, 128, seed=3).requires_grad_(True)
+    pos = torch.zeros(T, 1, heads, 64, requires_grad=True)
+    m = torch.ones(B, T, dtype=torch.bool)
+    if modes == "temporal":
+        m[1, T - max(1, T // 4):] = False
+    w = {"p.attn.in_proj.weight": torch.eye(2 * D), "p.attn.in_proj.bias": torch.zeros(2 * D),
+         "p.attn.out_proj.weight": torch.eye(D), "p.attn.out_proj.bias": torch.zeros(D)}
+    kk = (k.view(B, T, P, heads, 64) + pos).flatten(1, 2).requires_grad_(True)
+    vv = (v.view(B, T, P, heads, 64) + pos).flatten(1, 2).requires_grad_(True)
+    kk.retain_grad(), vv.retain_grad()
+    out = ref_cpu.decoder_attention(q.reshape(B, 1, 2 * D), kk, vv, m.repeat_interleave(P, dim=-1), w, "p.", heads, T,
+                                    attn_mode=attn_mode)
+    dmix = rnd(B, D, seed=4)
+    (out.reshape(B, D) * dmix).sum().backward()
+
+    kd, vd = k.to(dtype).reshape(B, S, D).cuda(), v.to(dtype).reshape(B, S, D).cuda()
+    qd, md = q.detach().reshape(B, 2 * D).cuda(), m.to(torch.uint8).cuda()
+    new = lambda *shape: torch.empty(*shape, device="cuda")
+    sc, aw = new(B, heads, S), new(B, heads, S)
+    capi.decoder_attn_modes_fwd(qd, kd, md, bits, sc, aw, B, T, P, heads)
+    # each enabled mode contributes weights that sum to T (frame) or P (temporal) per (clip, head)
+    want_sum = (T if "frame" in attn_mode else 0) + (P if "temporal" in attn_mode else 0)
+    close(aw.sum(-1), torch.full((B, heads), float(want_sum)), 1e-3 * want_sum, msg="weights sum")
+    splits = 3
+    ws = new(capi.decoder_attn_workspace_bytes(B, heads, 64, splits) // 4)
+    mix, stats = new(B, D), new(B, heads, 2)
+    capi.decoder_attn_fwd(qd, kd, vd, md, mix, stats, ws, splits, B, T, P, heads, ext_weights=aw)
+    scale = out.abs().max().item()
+    close(mix, out.reshape(B, D), 2e-5 * max(1.0, scale), 1e-4, "forward")
+    dsc = new(B, heads, S)
+    capi.decoder_attn_modes_bwd(sc, vd, dmix.cuda(), bits, new(B, heads, S), dsc, B, T, P, heads)
+    ws2 = new(capi.decoder_attn_bwd_workspace_bytes(B, T, heads) // 4)
+    dq, dpos, dk, dv = new(B, 2 * D), new(T, D), new(B, S, D), new(B, S, D)
+    capi.decoder_attn_bwd(qd, kd, vd, md, dmix.cuda(), None, None, dq, dpos, ws2, B, T, P, heads, dk=dk, dv=dv,
+                          ext_weights=aw, ext_dscores=dsc)
+    gs = max(1.0, q.grad.abs().max().item())
+    close(dq, q.grad.reshape(B, 2 * D), 5e-5 * gs, 2e-4, "dq")
+    close(dk, kk.grad.reshape(B, S, D), 5e-6 * gs, 2e-4, "dk")
+    close(dv, vv.grad.reshape(B, S, D), 5e-6 * gs, 2e-4, "dv")
+    close(dpos, pos.grad.reshape(T, D), 1e-4 * gs, 2e-4, "dpos")
+
+
 @pytest.mark.parametrize("B,N,K", [(2, 8, 128), (16, 1536, 768), (16, 768, 3072), (9, 100, 64)])
 def test_linear_backward(capi, B, N, K):
     x, w, dy = rnd(B, K, seed=5), rnd(N, K, seed=6, scale=K ** -0.5), rnd(B, N, seed=7)
@@ -134,7 +188,8 @@ def make_detector(case, precision):
     return det.to("cuda")
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_nopos", "tiny_augq", "tiny_adapter_nln", "tiny_adapter_ln", "small", "small14", "vitb16_cfg1"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_nopos", "tiny_augq", "tiny_adapter_nln", "tiny_adapter_ln", "small", "small14", "vitb16_cfg1",
+                                  "tiny_global", "tiny_attnmode"])
 def test_train_step_contract_matches_reference(name):
     """fp32 path: gradients of every decoder parameter after backward(mean loss), then two SGD steps
     on the same batch, against the reference's own autograd / optimizer results."""

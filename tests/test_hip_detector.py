@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-3
 BF16_TOL = 5e-2
-SUPPORTED = ["tiny", "tiny_stride", "tiny_nopos", "tiny_augq", "small", "small14", "tiny_adapter_nln", "tiny_adapter_ln"]
+SUPPORTED = ["tiny", "tiny_stride", "tiny_nopos", "tiny_augq", "small", "small14", "tiny_adapter_nln", "tiny_adapter_ln",
+             "tiny_global", "tiny_attnmode"]
 
 
 def make_detector(case, precision):

@@ -82,7 +82,7 @@ def test_unbuilt_variants_raise():
     cfg = make_config("tiny", adapter__type="normal", adapter__struct={"type": "768-bn", "x": 32})
     with pytest.raises(NotImplementedError):
         Detector(cfg, 4, None)
-    cfg = make_config("tiny", op_mode__global_prediction=1)
+    cfg = make_config("tiny", foundation="dinov2")
     with pytest.raises(NotImplementedError):
         Detector(cfg, 4, None)
 
@@ -126,3 +126,31 @@ def test_clip_transform_geometry_and_host_path():
     assert out.shape == (1, 3, 32, 32)
     lv = (out * torch.tensor(t.STD).view(1, 3, 1, 1) + torch.tensor(t.MEAN).view(1, 3, 1, 1)) * 255.0
     assert (lv - lv.round()).abs().max() < 1e-3
+
+
+def test_ema_teacher_update_and_schedule():
+    """`EmaTeacher` (reference `src/trainer.py:66-69`, `:179-190`): deep copy, p_t <- (1-r) p_t + r p after
+    every step, teaching switches on once teach_at < steps.  Host logic only (no forward)."""
+    import torch
+    from dfd_clip_amd.detector import Detector
+    from dfd_clip_amd.harness import EmaTeacher
+    cfg = make_config("tiny", decode_mode="index", decode_indices=[0, 1])
+    model = Detector(cfg, 4, None, precision="fp32")
+    teacher = EmaTeacher(model, ema_ratio=0.25, teach_at=2)
+    assert teacher.module is not model
+    before = {n: p.detach().clone() for n, p in teacher.module.named_parameters()}
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.requires_grad:
+                p.add_(1.0)
+    states = []
+    for _ in range(3):
+        teacher.update(model)
+        states.append(teacher.teaching)
+    assert states == [False, False, True]       # teach_at=2 < steps=3
+    for (n, pt), (_, pm) in zip(teacher.module.named_parameters(), model.named_parameters()):
+        if pm.requires_grad:  # three EMA steps towards p+1: 1 - 0.75^3
+            torch.testing.assert_close(pt, before[n] + (1 - 0.75 ** 3), atol=1e-6, rtol=0)
+        else:
+            torch.testing.assert_close(pt, before[n], atol=1e-6, rtol=0)
+        assert not pt.requires_grad or pm.requires_grad
