@@ -50,8 +50,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.0f - 2.0f / (e + 1.0f);
 }
 
-template <typename T>
-__global__ __launch_bounds__(1024) void decoder_attn_partial_kernel(const float* __restrict__ q, const T* __restrict__ k,
+template <typename T, int MAXT>
+__global__ __launch_bounds__(MAXT) void decoder_attn_partial_kernel(const float* __restrict__ q, const T* __restrict__ k,
                                                                     const T* __restrict__ v,
                                                                     const uint8_t* __restrict__ frame_mask,
                                                                     const float* __restrict__ ext_w,
@@ -84,43 +84,55 @@ __global__ __launch_bounds__(1024) void decoder_attn_partial_kernel(const float*
   const T* kb = k + (int64_t)b * S * D + hd * HD + sub * 8;
   const T* vb = v + (int64_t)b * S * D + hd * HD + sub * 8;
   const uint8_t* mb = frame_mask + (int64_t)b * T_frames;
-  // every lane of an 8-lane group walks the same rows, so the shuffles below are convergent
-  for (int s = s_begin + rs; s < s_end; s += R) {
-    float kk[8], vv[8];
-    Ld8<T>::load(kb + (int64_t)s * D, kk);
-    Ld8<T>::load(vb + (int64_t)s * D, vv);
-    float ds = 0.f, dc = 0.f, l1 = 0.f;
+  // every lane of an 8-lane group walks the same rows, so the shuffles below are convergent.
+  // Rows are taken four at a time with all eight loads issued before the first use: the loop is a
+  // latency chain otherwise (a dozen dependent HBM round trips per thread).
+  constexpr int UN = 4;
+  for (int s0 = s_begin + rs; s0 < s_end; s0 += UN * R) {
+    float kk[UN][8], vv[UN][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      ds = fmaf(qs[e], kk[e], ds);
-      dc = fmaf(qc[e] * 0.125f, kk[e], dc);
-      l1 += fabsf(qc[e] - kk[e]);
+    for (int u = 0; u < UN; ++u) {
+      const int s = min(s0 + u * R, S - 1);  // clamp: rows past the end are loaded but not used
+      Ld8<T>::load(kb + (int64_t)s * D, kk[u]);
+      Ld8<T>::load(vb + (int64_t)s * D, vv[u]);
     }
-    ds = group8_sum(ds);
-    dc = group8_sum(dc);
-    l1 = group8_sum(l1);
-    if (mb[s / patches]) {
-      float p;
-      if (ext_w != nullptr) {
-        // attn_mode: the softmax-branch weight was computed by the grouped-softmax pass
-        p = ext_w[((int64_t)b * heads + hd) * S + s];
-      } else {
-        if (ds > mx) {
-          const float alpha = __expf(mx - ds);
-          l *= alpha;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) as[e] *= alpha;
-          mx = ds;
-        }
-        p = __expf(ds - mx);
-        l += p;
-      }
-      const float gate = 2.0f / (1.0f + __expf(l1 * 0.125f));  // 2·sigmoid(−l1/√d)
-      const float c = fast_tanh(dc) * gate;
+    for (int u = 0; u < UN; ++u) {
+      const int s = s0 + u * R;
+      if (s >= s_end) break;  // uniform within the 8-lane group (and the wave's other groups only skip work)
+      float ds = 0.f, dc = 0.f, l1 = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        as[e] = fmaf(p, vv[e], as[e]);
-        ac[e] = fmaf(c, vv[e], ac[e]);
+        ds = fmaf(qs[e], kk[u][e], ds);
+        dc = fmaf(qc[e] * 0.125f, kk[u][e], dc);
+        l1 += fabsf(qc[e] - kk[u][e]);
+      }
+      ds = group8_sum(ds);
+      dc = group8_sum(dc);
+      l1 = group8_sum(l1);
+      if (mb[s / patches]) {
+        float p;
+        if (ext_w != nullptr) {
+          // attn_mode: the softmax-branch weight was computed by the grouped-softmax pass
+          p = ext_w[((int64_t)b * heads + hd) * S + s];
+        } else {
+          if (ds > mx) {
+            const float alpha = __expf(mx - ds);
+            l *= alpha;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) as[e] *= alpha;
+            mx = ds;
+          }
+          p = __expf(ds - mx);
+          l += p;
+        }
+        const float gate = 2.0f / (1.0f + __expf(l1 * 0.125f));  // 2·sigmoid(−l1/√d)
+        const float c = fast_tanh(dc) * gate;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          as[e] = fmaf(p, vv[u][e], as[e]);
+          ac[e] = fmaf(c, vv[u][e], ac[e]);
+        }
       }
     }
   }
@@ -158,25 +170,42 @@ __global__ __launch_bounds__(1024) void decoder_attn_partial_kernel(const float*
 __global__ void decoder_attn_combine_kernel(const float* __restrict__ ws, float* __restrict__ mix,
                                             float* __restrict__ mix_softmax, float* __restrict__ stats, int splits,
                                             int heads) {
+  extern __shared__ float cw[];  // [heads][splits] rescale weights exp(m_split − M)
+  __shared__ float sM[16], sL[16];
   const int b = blockIdx.x;
   const int hd = threadIdx.x / HD, c = threadIdx.x % HD;
-  const float* base = ws + ((int64_t)b * splits * heads + hd) * PART;
-  float M = -INFINITY;
-  for (int s = 0; s < splits; ++s) M = fmaxf(M, base[(int64_t)s * heads * PART]);
-  float L = 0.f, As = 0.f, Ac = 0.f;
+  const float* base = ws + (int64_t)b * splits * heads * PART;
+  // stage 1: one wave-parallel pass over the (split, head) states instead of a serial chain per thread
+  if (c < 64) {
+    float M = -INFINITY;
+    for (int s = c; s < splits; s += 64) M = fmaxf(M, base[((int64_t)s * heads + hd) * PART]);
+    M = wave_max(M);
+    float L = 0.f;
+    for (int s = c; s < splits; s += 64) {
+      const float* o = base + ((int64_t)s * heads + hd) * PART;
+      const float w = (o[0] == -INFINITY) ? 0.f : __expf(o[0] - M);
+      cw[hd * splits + s] = w;
+      L = fmaf(o[1], w, L);
+    }
+    L = wave_sum(L);
+    if (c == 0) { sM[hd] = M; sL[hd] = L; }
+  }
+  __syncthreads();
+  const float L = sL[hd];
+  float As = 0.f, Ac = 0.f;
+  const float* col = base + (int64_t)hd * PART + 2 + c;
+#pragma unroll 8
   for (int s = 0; s < splits; ++s) {
-    const float* o = base + (int64_t)s * heads * PART;
-    const float w = (o[0] == -INFINITY) ? 0.f : __expf(o[0] - M);
-    L = fmaf(o[1], w, L);
-    As = fmaf(o[2 + c], w, As);
-    Ac += o[2 + HD + c];
+    const float* o = col + (int64_t)s * heads * PART;
+    As = fmaf(o[0], cw[hd * splits + s], As);
+    Ac += o[HD];
   }
   // (softmax branch + CoDA branch) / n_act, n_act = 2 (models.py:140-142).  All keys masked:
   // L == 0 -> NaN, as the reference's softmax over all -inf.
   mix[(int64_t)b * heads * HD + threadIdx.x] = 0.5f * (As / L) + 0.5f * Ac;
   if (mix_softmax != nullptr) mix_softmax[(int64_t)b * heads * HD + threadIdx.x] = As / L;
   if (c == 0) {
-    stats[((int64_t)b * heads + hd) * 2 + 0] = M;
+    stats[((int64_t)b * heads + hd) * 2 + 0] = sM[hd];
     stats[((int64_t)b * heads + hd) * 2 + 1] = L;
   }
 }
@@ -465,14 +494,15 @@ extern "C" int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(splits, B), block(threads);
   float* ws = static_cast<float*>(workspace);
-  if (kv_dtype == DFD_F32)
-    hipLaunchKernelGGL((decoder_attn_partial_kernel<float>), grid, block, lds, st, q, static_cast<const float*>(k),
-                       static_cast<const float*>(v), frame_mask, ext_weights, ws, splits, T, patches, heads, R);
-  else
-    hipLaunchKernelGGL((decoder_attn_partial_kernel<bf16_t>), grid, block, lds, st, q, static_cast<const bf16_t*>(k),
-                       static_cast<const bf16_t*>(v), frame_mask, ext_weights, ws, splits, T, patches, heads, R);
+#define PARTIAL_LAUNCH(KT, MT)                                                                                      \
+  hipLaunchKernelGGL((decoder_attn_partial_kernel<KT, MT>), grid, block, lds, st, q, static_cast<const KT*>(k),     \
+                     static_cast<const KT*>(v), frame_mask, ext_weights, ws, splits, T, patches, heads, R)
+  if (kv_dtype == DFD_F32) { if (threads <= 512) PARTIAL_LAUNCH(float, 512); else PARTIAL_LAUNCH(float, 1024); }
+  else { if (threads <= 512) PARTIAL_LAUNCH(bf16_t, 512); else PARTIAL_LAUNCH(bf16_t, 1024); }
+#undef PARTIAL_LAUNCH
   DFD_CHECK_LAUNCH("dfd_decoder_attn_fwd(partial)");
-  hipLaunchKernelGGL(decoder_attn_combine_kernel, dim3(B), dim3(heads * HD), 0, st, ws, mix, mix_softmax, stats, splits, heads);
+  hipLaunchKernelGGL(decoder_attn_combine_kernel, dim3(B), dim3(heads * HD), (size_t)heads * splits * sizeof(float), st, ws, mix,
+                     mix_softmax, stats, splits, heads);
   DFD_CHECK_LAUNCH("dfd_decoder_attn_fwd(combine)");
   return DFD_OK;
 }

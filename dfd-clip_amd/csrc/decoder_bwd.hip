@@ -41,8 +41,8 @@ __device__ __forceinline__ float group8_sum(float v) {
 __device__ __forceinline__ float sgn(float x) { return (float)(x > 0.f) - (float)(x < 0.f); }
 
 // grid (T, B).  part layout per (b, t): [heads][128] dq (softmax query | CoDA query), then [heads*64] dpos.
-template <typename T, typename G>
-__global__ __launch_bounds__(1024) void decoder_attn_bwd_kernel(const float* __restrict__ q, const T* __restrict__ k,
+template <typename T, typename G, int MAXT>
+__global__ __launch_bounds__(MAXT) void decoder_attn_bwd_kernel(const float* __restrict__ q, const T* __restrict__ k,
                                                                 const T* __restrict__ v,
                                                                 const uint8_t* __restrict__ frame_mask,
                                                                 const float* __restrict__ dmix,
@@ -92,49 +92,62 @@ __global__ __launch_bounds__(1024) void decoder_attn_bwd_kernel(const float* __r
     const int s0 = t * patches;
     const T* kb = k + ((int64_t)b * S + s0) * D + hd * HD + sub * 8;
     const T* vb = v + ((int64_t)b * S + s0) * D + hd * HD + sub * 8;
-    for (int j = rs; j < patches; j += R) {
-      float kk[8], vv[8];
-      Ld8<T>::load(kb + (int64_t)j * D, kk);
-      Ld8<T>::load(vb + (int64_t)j * D, vv);
-      float s = 0.f, tt = 0.f, l1 = 0.f, dw = 0.f;
+    // two rows per trip, all four loads issued before the first use (the trip is a latency chain otherwise)
+    constexpr int UN = 2;
+    for (int j0 = rs; j0 < patches; j0 += UN * R) {
+      float kq[UN][8], vq[UN][8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        s = fmaf(qs[e] * 0.125f, kk[e], s);
-        tt = fmaf(qc[e] * 0.125f, kk[e], tt);
-        l1 += fabsf(qc[e] - kk[e]);
-        dw = fmaf(dm[e], vv[e], dw);
+      for (int u = 0; u < UN; ++u) {
+        const int j = min(j0 + u * R, patches - 1);
+        Ld8<T>::load(kb + (int64_t)j * D, kq[u]);
+        Ld8<T>::load(vb + (int64_t)j * D, vq[u]);
       }
-      s = group8_sum(s);
-      tt = group8_sum(tt);
-      l1 = group8_sum(l1);
-      dw = group8_sum(dw);
-      const int64_t wi = ((int64_t)b * heads + hd) * S + s0 + j;
-      const float aw = ext ? ext_w[wi] : __expf(s - M) * invL;      // softmax(-branch) weight
-      const float g = 2.0f / (1.0f + __expf(l1 * 0.125f));         // 2·sigmoid(−l1/8)
-      const float e2 = __expf(2.0f * tt);
-      const float th = 1.0f - 2.0f / (e2 + 1.0f);                  // tanh
-      const float w = 0.5f * (aw + th * g);
-      const float ds = ext ? ext_ds[wi] : aw * (0.5f * dw - dlt);
-      const float dc = 0.5f * dw;
-      const float dt = dc * g * (1.0f - th * th);
-      const float dL = -(dc * th) * g * (1.0f - 0.5f * g) * 0.125f;
-      a1 += ds;
-      a2 += dt;
-      a3 += w;
-      float dkk[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float sg = sgn(qc[e] - kk[e]) * dL;
-        dqs[e] = fmaf(ds * 0.125f, kk[e], dqs[e]);
-        dqc[e] = fmaf(dt * 0.125f, kk[e], dqc[e]) + sg;
-        sv[e] += sg;
-        dkk[e] = (ds * qs[e] + dt * qc[e]) * 0.125f - sg;
-      }
-      if (dk_out != nullptr) {
-        G* ko = dk_out + ((int64_t)b * S + s0 + j) * D + hd * HD + sub * 8;
-        G* vo = dv_out + ((int64_t)b * S + s0 + j) * D + hd * HD + sub * 8;
+      for (int u = 0; u < UN; ++u) {
+        const int j = j0 + u * R;
+        if (j >= patches) break;
+        const float* kk = kq[u];
+        const float* vv = vq[u];
+        float s = 0.f, tt = 0.f, l1 = 0.f, dw = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ko[e] = from_f32<G>(dkk[e]); vo[e] = from_f32<G>(w * dm[e]); }
+        for (int e = 0; e < 8; ++e) {
+          s = fmaf(qs[e] * 0.125f, kk[e], s);
+          tt = fmaf(qc[e] * 0.125f, kk[e], tt);
+          l1 += fabsf(qc[e] - kk[e]);
+          dw = fmaf(dm[e], vv[e], dw);
+        }
+        s = group8_sum(s);
+        tt = group8_sum(tt);
+        l1 = group8_sum(l1);
+        dw = group8_sum(dw);
+        const int64_t wi = ((int64_t)b * heads + hd) * S + s0 + j;
+        const float aw = ext ? ext_w[wi] : __expf(s - M) * invL;      // softmax(-branch) weight
+        const float g = 2.0f / (1.0f + __expf(l1 * 0.125f));         // 2·sigmoid(−l1/8)
+        const float e2 = __expf(2.0f * tt);
+        const float th = 1.0f - 2.0f / (e2 + 1.0f);                  // tanh
+        const float w = 0.5f * (aw + th * g);
+        const float ds = ext ? ext_ds[wi] : aw * (0.5f * dw - dlt);
+        const float dc = 0.5f * dw;
+        const float dt = dc * g * (1.0f - th * th);
+        const float dL = -(dc * th) * g * (1.0f - 0.5f * g) * 0.125f;
+        a1 += ds;
+        a2 += dt;
+        a3 += w;
+        float dkk[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sg = sgn(qc[e] - kk[e]) * dL;
+          dqs[e] = fmaf(ds * 0.125f, kk[e], dqs[e]);
+          dqc[e] = fmaf(dt * 0.125f, kk[e], dqc[e]) + sg;
+          sv[e] += sg;
+          dkk[e] = (ds * qs[e] + dt * qc[e]) * 0.125f - sg;
+        }
+        if (dk_out != nullptr) {
+          G* ko = dk_out + ((int64_t)b * S + s0 + j) * D + hd * HD + sub * 8;
+          G* vo = dv_out + ((int64_t)b * S + s0 + j) * D + hd * HD + sub * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { ko[e] = from_f32<G>(dkk[e]); vo[e] = from_f32<G>(w * dm[e]); }
+        }
       }
     }
   } else if (dk_out != nullptr) {
@@ -427,19 +440,24 @@ extern "C" int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* part = static_cast<float*>(workspace);
   const dim3 grid(T, B), block(threads);
-#define BWD_LAUNCH(KT, GT)                                                                                                  \
+#define BWD_LAUNCH1(KT, GT, MT)                                                                                              \
   do {                                                                                                                      \
     if (lds > 64 * 1024)                                                                                                    \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decoder_attn_bwd_kernel<KT, GT>),                             \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decoder_attn_bwd_kernel<KT, GT, MT>),                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
-    hipLaunchKernelGGL((decoder_attn_bwd_kernel<KT, GT>), grid, block, lds, st, q, static_cast<const KT*>(k),                  \
+    hipLaunchKernelGGL((decoder_attn_bwd_kernel<KT, GT, MT>), grid, block, lds, st, q, static_cast<const KT*>(k),              \
                        static_cast<const KT*>(v), frame_mask, dmix, mix_softmax, stats, ext_weights, ext_dscores, part,      \
-                       static_cast<GT*>(dk),                                                                                  \
-                       static_cast<GT*>(dv), T, patches, heads, R);                                                         \
+                       static_cast<GT*>(dk), static_cast<GT*>(dv), T, patches, heads, R);                                    \
+  } while (0)
+  // blocks of <= 512 threads (every even head count) get the 256-register budget: no spills with two rows in flight
+#define BWD_LAUNCH(KT, GT)                                                                                                  \
+  do {                                                                                                                      \
+    if (threads <= 512) BWD_LAUNCH1(KT, GT, 512); else BWD_LAUNCH1(KT, GT, 1024);                                           \
   } while (0)
   const bool gb = dk && dkv_dtype == DFD_BF16;
   if (kv_dtype == DFD_F32) { if (gb) BWD_LAUNCH(float, bf16_t); else BWD_LAUNCH(float, float); }
   else { if (gb) BWD_LAUNCH(bf16_t, bf16_t); else BWD_LAUNCH(bf16_t, float); }
+#undef BWD_LAUNCH1
 #undef BWD_LAUNCH
   DFD_CHECK_LAUNCH("dfd_decoder_attn_bwd");
   const int total = B * 2 * D + (dpos ? T * D : 0);
