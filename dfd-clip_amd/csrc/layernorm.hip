@@ -101,6 +101,127 @@ extern "C" int dfd_layernorm(const float* x, int64_t ldx, const float* gamma, co
   return launch_ln<bf16_t>(x, ldx, gamma, beta, y, ldy, rows, cols, eps, st);
 }
 
+// ---- residual add + LayerNorm ----------------------------------------------------------------
+// x[row] += delta[row] (f32 residual stream, updated in place), y[row] = LayerNorm(x[row]).
+// The bf16 encoder path lets out_proj / c_proj write their output as a bf16 `delta` with a plain
+// store epilogue instead of a read-modify-write of the f32 stream inside the GEMM (a 128 MB burst
+// per wave of tiles with every CU in its epilogue at once), and folds the add into the LayerNorm
+// that follows — exactly torch autocast's dataflow (Linear output in bf16, added to the fp32 stream).
+// Bytes per row: cols * (4 + sizeof(delta) + 4 + sizeof(y)).
+template <typename DeltaT, typename OutT, int SLABS>
+__global__ __launch_bounds__(256) void add_layernorm_rows_kernel(float* __restrict__ x, int64_t ldx,
+                                                                 const DeltaT* __restrict__ delta, int64_t ldd,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, OutT* __restrict__ y,
+                                                                 int64_t ldy, int64_t rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* xr = x + row * ldx;
+  const DeltaT* dr = delta + row * ldd;
+  f32x4 v[SLABS];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < SLABS; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < cols) {
+      v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+      if constexpr (sizeof(DeltaT) == 4) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dr + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] += d[j];
+      } else {
+        const bf16x4 d = *reinterpret_cast<const bf16x4*>(dr + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] += (float)d[j];
+      }
+      *reinterpret_cast<f32x4*>(xr + c) = v[i];
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    } else {
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < SLABS; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < cols) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[i][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+  OutT* yr = y + row * ldy;
+#pragma unroll
+  for (int i = 0; i < SLABS; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < cols) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+      if constexpr (sizeof(OutT) == 4) {
+        *reinterpret_cast<f32x4*>(yr + c) = o;
+      } else {
+        bf16x4 ob;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)o[j];
+        *reinterpret_cast<bf16x4*>(yr + c) = ob;
+      }
+    }
+  }
+}
+
+template <typename DeltaT, typename OutT>
+static int launch_add_ln(float* x, int64_t ldx, const void* delta, int64_t ldd, const float* g, const float* b, void* y,
+                         int64_t ldy, int64_t rows, int cols, float eps, hipStream_t st) {
+  const int slabs = (cols + 255) / 256;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  const DeltaT* dd = static_cast<const DeltaT*>(delta);
+  OutT* yo = static_cast<OutT*>(y);
+#define ALN_CASE(S)                                                                                                   \
+  case S:                                                                                                             \
+    hipLaunchKernelGGL((add_layernorm_rows_kernel<DeltaT, OutT, S>), grid, block, 0, st, x, ldx, dd, ldd, g, b, yo, ldy, rows, \
+                       cols, eps);                                                                                    \
+    break;
+  switch (slabs) {
+    ALN_CASE(1) ALN_CASE(2) ALN_CASE(3) ALN_CASE(4) ALN_CASE(5) ALN_CASE(6) ALN_CASE(7) ALN_CASE(8)
+    default:
+      dfd_set_error("dfd_add_layernorm: cols=%d > 2048 unsupported", cols);
+      return DFD_ERR_INVALID_ARG;
+  }
+#undef ALN_CASE
+  DFD_CHECK_LAUNCH("dfd_add_layernorm");
+  return DFD_OK;
+}
+
+extern "C" int dfd_add_layernorm(float* x, int64_t ldx, const void* delta, int64_t ldd, int delta_dtype, const float* gamma,
+                                 const float* beta, void* y, int64_t ldy, int y_dtype, int64_t rows, int cols, float eps,
+                                 void* stream) {
+  DFD_REQUIRE(x && delta && gamma && beta && y, "dfd_add_layernorm: null pointer");
+  DFD_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "dfd_add_layernorm: cols=%d must be a multiple of 4, <= 2048", cols);
+  DFD_REQUIRE(ldx >= cols && ldd >= cols && ldy >= cols && ldx % 4 == 0 && ldd % 4 == 0 && ldy % 4 == 0,
+              "dfd_add_layernorm: bad leading dimension (ldx=%lld ldd=%lld ldy=%lld)", (long long)ldx, (long long)ldd, (long long)ldy);
+  DFD_REQUIRE(dfd_aligned16(x) && dfd_aligned16(gamma) && dfd_aligned16(beta) && ((uintptr_t)y & 7) == 0 && ((uintptr_t)delta & 7) == 0,
+              "dfd_add_layernorm: pointers must be 16-byte aligned (8 for bf16 operands)");
+  DFD_REQUIRE((delta_dtype == DFD_F32 || delta_dtype == DFD_BF16) && (y_dtype == DFD_F32 || y_dtype == DFD_BF16),
+              "dfd_add_layernorm: delta_dtype=%d y_dtype=%d", delta_dtype, y_dtype);
+  DFD_REQUIRE(static_cast<const void*>(x) != y && delta != y, "dfd_add_layernorm: y must not alias x or delta");
+  if (rows == 0) return DFD_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (delta_dtype == DFD_F32) {
+    if (y_dtype == DFD_F32) return launch_add_ln<float, float>(x, ldx, delta, ldd, gamma, beta, y, ldy, rows, cols, eps, st);
+    return launch_add_ln<float, bf16_t>(x, ldx, delta, ldd, gamma, beta, y, ldy, rows, cols, eps, st);
+  }
+  if (y_dtype == DFD_F32) return launch_add_ln<bf16_t, float>(x, ldx, delta, ldd, gamma, beta, y, ldy, rows, cols, eps, st);
+  return launch_add_ln<bf16_t, bf16_t>(x, ldx, delta, ldd, gamma, beta, y, ldy, rows, cols, eps, st);
+}
+
 // ---- patchify -----------------------------------------------------------------------------
 // One thread per 4 consecutive output columns of one patch row.  Output column
 // k = c*p*p + i*p + j reads frame pixel (c, gy*p + i, gx*p + j).  Reads are contiguous along j

@@ -24,6 +24,7 @@ epilogue: `[N*P, D]` per selected layer, CLS row dropped, temporal positional em
 layer that cannot reach any exported tensor.
 """
 import contextlib
+import os
 
 import torch
 from torch import nn
@@ -106,6 +107,9 @@ class VisionTransformer(nn.Module):
         self.pixel_mean = (0.48145466, 0.4578275, 0.40821073)
         self.pixel_std = (0.26862954, 0.26130258, 0.27577711)
         self.antialias = True
+        # bf16 path: residual branches are stored as bf16 deltas and added inside the next LayerNorm
+        # (see `_residual`); the fp32 parity path keeps the read-modify-write epilogue
+        self.deferred_residual = precision == "bf16" and os.environ.get("DFD_DEFERRED_RESIDUAL", "1") != "0"
 
     # ---- derived device-side operands ---------------------------------------------------
     @property
@@ -172,6 +176,7 @@ class VisionTransformer(nn.Module):
                 x=torch.zeros(Mp, D, device=dev, dtype=torch.float32), h=torch.zeros(Mp, D, device=dev, dtype=act),
                 mix=torch.zeros(Mp, D, device=dev, dtype=act), u=torch.zeros(Mp, 4 * D, device=dev, dtype=act),
                 patches=torch.zeros(Pp, kpad, device=dev, dtype=act),
+                delta=torch.zeros(Mp, D, device=dev, dtype=act) if self.deferred_residual else None, pending=False,
                 qkv=[torch.zeros(Mp, 3 * D, device=dev, dtype=act) for _ in range(keep_layers)])
             if len(self._ws) > 6:
                 self._ws.clear()
@@ -202,15 +207,43 @@ class VisionTransformer(nn.Module):
         capi.gemm(ws["patches"], p["w_patch"], ws["x"], None, capi.EPI_PATCH_EMBED, m=n * P, pos=p["pos"], cls=p["cls"],
                   tokens=self.tokens)
         M = n * self.tokens
+        ws["pending"] = False
         capi.layernorm(ws["x"][:M], p["ln_pre"][0], p["ln_pre"][1], ws["x"][:M])
+
+    def _ln(self, ws, gb, M):
+        """h = LayerNorm(x).  On the bf16 path a residual branch that has not been added yet
+        (`ws["pending"]`: out_proj / c_proj wrote it to `ws["delta"]`) is folded in first:
+        x += delta happens inside the same pass over the rows (dfd_add_layernorm)."""
+        x, h = ws["x"], ws["h"]
+        if ws.get("pending"):
+            capi.add_layernorm(x[:M], ws["delta"][:M], gb[0], gb[1], h[:M])
+            ws["pending"] = False
+        else:
+            capi.layernorm(x[:M], gb[0], gb[1], h[:M])
+
+    def _residual(self, ws, a, w, b, M):
+        """x = x + Linear(a) (model.py:222-223).  fp32 path: read-modify-write of x in the GEMM
+        epilogue.  bf16 path: the GEMM stores its output as a bf16 delta (plain store epilogue, a
+        quarter of the epilogue bytes) and the add is deferred to the LayerNorm that follows."""
+        if self.deferred_residual:
+            assert not ws.get("pending")
+            capi.gemm(a, w, ws["delta"], b, capi.EPI_BIAS, m=M)
+            ws["pending"] = True
+        else:
+            capi.gemm(a, w, ws["x"], b, capi.EPI_BIAS_RESIDUAL, m=M)
+
+    def _flush(self, ws, M):
+        """Materialise x when something other than a LayerNorm reads it next."""
+        if ws.get("pending"):
+            ws["x"][:M] += ws["delta"][:M]
+            ws["pending"] = False
 
     def _block(self, ws, bp, qkv, M, n, kv_only=False, export=None):
         """One residual attention block (model.py:220-226).  `export` = (k_out, v_out, tpos, T)
         makes the QKV epilogue also write the decoder operands; `kv_only` stops after the
         projection (nothing after it can reach an exported tensor)."""
-        D = self.width
-        x, h = ws["x"], ws["h"]
-        capi.layernorm(x[:M], bp["ln1"][0], bp["ln1"][1], h[:M])
+        h = ws["h"]
+        self._ln(ws, bp["ln1"], M)
         if export is not None:
             capi.gemm(h, bp["w_qkv"], qkv, bp["b_qkv"], capi.EPI_QKV_EXPORT, m=M, pos=export[2], k_export=export[0],
                       v_export=export[1], tokens=self.tokens, frames_per_clip=export[3])
@@ -219,10 +252,10 @@ class VisionTransformer(nn.Module):
         if kv_only:
             return
         capi.attention_fwd(qkv, ws["mix"], n, self.tokens, self.heads)
-        capi.gemm(ws["mix"], bp["w_out"], x, bp["b_out"], capi.EPI_BIAS_RESIDUAL, m=M)
-        capi.layernorm(x[:M], bp["ln2"][0], bp["ln2"][1], h[:M])
+        self._residual(ws, ws["mix"], bp["w_out"], bp["b_out"], M)
+        self._ln(ws, bp["ln2"], M)
         capi.gemm(h, bp["w_fc"], ws["u"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M)
-        capi.gemm(ws["u"], bp["w_proj"], x, bp["b_proj"], capi.EPI_BIAS_RESIDUAL, m=M)
+        self._residual(ws, ws["u"], bp["w_proj"], bp["b_proj"], M)
 
     @torch.no_grad()
     def forward(self, x, with_out=False, with_q=False):
@@ -245,6 +278,7 @@ class VisionTransformer(nn.Module):
             if with_q:
                 d["q"] = t[:, :, 0]
             if with_out:
+                self._flush(ws, M)
                 d["out"] = ws["x"][:M].view(n, tok, D).clone()
             result.append(d)
         return result

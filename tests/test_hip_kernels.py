@@ -56,6 +56,26 @@ def test_layernorm(capi, rows, cols):
     assert_close(xd, want, 2e-5, msg="in place")
 
 
+@pytest.mark.parametrize("rows,cols", [(1, 128), (7, 768), (1000, 768), (33, 1024), (257, 2048)])
+@pytest.mark.parametrize("delta_dtype", [torch.float32, torch.bfloat16])
+def test_add_layernorm(capi, rows, cols, delta_dtype):
+    """x += delta in place, y = LayerNorm(x): the deferred residual of the bf16 encoder path."""
+    x = rnd(rows, cols, seed=1, scale=3.0) + 0.5
+    d = rnd(rows, cols, seed=4).to(delta_dtype)
+    g, b = 1 + 0.1 * rnd(cols, seed=2), 0.1 * rnd(cols, seed=3)
+    x_new = x + d.float()
+    want = F.layer_norm(x_new, (cols,), g, b, 1e-5)
+    for out_dtype, tol in ((torch.float32, dict(atol=2e-5)), (torch.bfloat16, dict(atol=1e-5, rtol=2 ** -8))):
+        xd = x.clone().cuda()
+        out = torch.empty(rows, cols, device="cuda", dtype=out_dtype)
+        capi.add_layernorm(xd, d.cuda(), g.cuda(), b.cuda(), out)
+        assert torch.equal(xd.cpu(), x_new), "x must hold the exact fp32 sum"
+        assert_close(out, want, msg=str(out_dtype), **tol)
+    with pytest.raises(capi.DfdError):
+        xd = x.clone().cuda()
+        capi.add_layernorm(xd, d.cuda(), g.cuda(), b.cuda(), xd)  # y aliasing x is refused
+
+
 @pytest.mark.parametrize("res,patch,width", [(32, 16, 128), (224, 16, 256), (224, 14, 128)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_patch_embed_is_conv1_plus_cls_plus_pos(capi, res, patch, width, dtype):
