@@ -217,8 +217,10 @@ def main():
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        if os.path.exists(tpath):  # PMC-measured HBM bytes per launch; only valid for the shape it was measured on
+            tj = json.load(open(tpath))
+            if tj.get("shape") == {"M": launch_m, "N": 4 * width, "K": width}:
+                traffic = tj.get("hbm_bytes_per_launch")
         line = {
             "metric": f"1-sec clips/sec (30x224x224 frames) {args.arch}", "value": round(world * B * args.steps / dt, 3),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

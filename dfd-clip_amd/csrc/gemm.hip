@@ -322,6 +322,12 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
   return launch_gemm128<bf16_t, float>(a, epilogue, st);
 }
 
+// gemm_tn.hip: bf16 operands read through the transposing LDS load, no HBM transposes
+bool dfd_gemm_tn_supported(const void* A, int64_t lda, const void* B, int64_t ldb, int Ma, int Nb);
+int dfd_gemm_tn_splits(int64_t R, int Ma, int Nb);
+int dfd_gemm_tn_launch(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t R, int Ma, int Nb,
+                       float* slabs, hipStream_t st);
+
 extern "C" size_t dfd_gemm_at_b_workspace(int64_t R, int Ma, int Nb, int dtype) {
   if (R <= 0 || Ma <= 0 || Nb <= 0) return 0;
   int64_t Rp;
@@ -330,7 +336,12 @@ extern "C" size_t dfd_gemm_at_b_workspace(int64_t R, int Ma, int Nb, int dtype) 
   const size_t esz = dtype == DFD_F32 ? 4 : 2;
   size_t bytes = (size_t)(Ma + Nb) * Rp * esz;
   bytes = (bytes + 255) / 256 * 256;
-  return bytes + (size_t)splits * Ma * Nb * sizeof(float) + 256;
+  bytes += (size_t)splits * Ma * Nb * sizeof(float) + 256;
+  if (dtype == DFD_BF16 && Ma % 128 == 0 && Nb % 128 == 0) {
+    const size_t tn = (size_t)dfd_gemm_tn_splits(R, Ma, Nb) * Ma * Nb * sizeof(float) + 256;
+    if (tn > bytes) bytes = tn;
+  }
+  return bytes;
 }
 
 extern "C" int dfd_gemm_at_b(const void* A, int64_t lda, const void* B, int64_t ldb, int dtype, float* C, int64_t R, int Ma,
@@ -341,6 +352,8 @@ extern "C" int dfd_gemm_at_b(const void* A, int64_t lda, const void* B, int64_t 
   DFD_REQUIRE(dtype == DFD_F32 || dtype == DFD_BF16, "dfd_gemm_at_b: dtype=%d", dtype);
   DFD_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "dfd_gemm_at_b: workspace must be 256-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == DFD_BF16 && dfd_gemm_tn_supported(A, lda, B, ldb, Ma, Nb))
+    return dfd_gemm_tn_launch(A, lda, B, ldb, C, R, Ma, Nb, static_cast<float*>(workspace), st);
   if (dtype == DFD_F32) return launch_at_b<float>(A, lda, B, ldb, C, R, Ma, Nb, workspace, st);
   return launch_at_b<bf16_t>(A, lda, B, ldb, C, R, Ma, Nb, workspace, st);
 }

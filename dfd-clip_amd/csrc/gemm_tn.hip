@@ -1,0 +1,180 @@
+// C[Ma, Nb] (f32) = Aᵀ·B for tall row-major bf16 operands A [R, Ma], B [R, Nb]: the weight gradient
+// of a Linear applied to R = B·T·patches rows (adapter training, reference models.py:783-940 under
+// trainer.py:157-165).  The contraction index is the ROW index of both operands, so neither is
+// K-contiguous; instead of transposing them in HBM the tiles are staged row-major in LDS by
+// global_load_lds and read back through gfx950's transposing LDS read (ds_read_b64_tr_b16), which
+// hands each lane 4 consecutive contraction rows of one column — the v_mfma_f32_16x16x32_bf16 operand
+// layout (2 reads per 16x32 fragment).  A and B use the same row→k mapping, so any consistent order
+// of the contraction is fine.
+//
+// Tile 128(m) x 128(n) x 64 rows per step, 4 waves (2x2, 64x64 each, 64 accumulator registers),
+// two 32 KB LDS slots (2 workgroups per CU).  LDS image: plain 256-byte rows with the 16-byte chunk
+// XOR of cdna_hip_programming.md T10(b), off(row, ch) = 256*row + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3))),
+// applied on the global source address (LDS-DMA destinations are lane-linear): conflict-free for the
+// transposed reads.  Split over R: each grid.z slice accumulates its rows into its own f32 slab, a
+// fixed-order slab reduce follows (deterministic).  Rows past R come from a 16-byte zero constant.
+//
+// Bytes: every A row is read Nb/128 times and every B row Ma/128 times (L2/MALL absorbs most).
+#include "common.hpp"
+
+namespace {
+
+constexpr int TT = 128;            // tile side in m and n
+constexpr int TR = 64;             // contraction rows per step
+constexpr int ROWB = TT * 2;       // 256 B per LDS row
+constexpr int HALF = TR * ROWB;    // 16 KB: one operand's tile
+constexpr int SLOT = 2 * HALF;     // A tile | B tile
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+__device__ const uint4 kZero16 = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+struct TnArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  float* slabs;
+  int64_t lda, ldb, R;
+  int Ma, Nb, steps_per_split;
+};
+
+// one operand tile: 64 rows x 128 columns starting at (r0, c0); wave w stages rows 16w..16w+15
+__device__ __forceinline__ void stage(const bf16_t* __restrict__ src, int64_t ld, int64_t R, int64_t r0, int c0,
+                                      unsigned char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 16 * wave + 4 * i + (lane >> 4);
+    const int cpos = lane & 15;
+    const int ch = cpos ^ swz(row);
+    const int64_t gr = r0 + row;
+    const void* g = gr < R ? static_cast<const void*>(src + gr * ld + c0 + 8 * ch) : static_cast<const void*>(&kZero16);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(lds_tile + (16 * wave + 4 * i) * ROWB), 16, 0, 0);
+  }
+}
+
+// 16(col) x 32(row) operand fragment of the tile at columns col0.., rows k0..k0+31
+__device__ __forceinline__ bf16x8 frag(const unsigned char* lds_tile, int col0, int k0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int c0 = col0 >> 3;  // first 16-byte chunk of the 16 columns
+  const int r1 = k0 + 8 * g + q, r2 = r1 + 4;
+  const unsigned char* a1 = lds_tile + ROWB * r1 + 16 * ((c0 + (p >> 1)) ^ swz(r1)) + 8 * (p & 1);
+  const unsigned char* a2 = lds_tile + ROWB * r2 + 16 * ((c0 + (p >> 1)) ^ swz(r2)) + 8 * (p & 1);
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)a1);
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)a2);
+  short8 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 slots x (A tile | B tile)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * TT, n0 = blockIdx.x * TT;
+  const int64_t total_steps = (a.R + TR - 1) / TR;
+  const int64_t s_begin = (int64_t)blockIdx.z * a.steps_per_split;
+  int64_t s_end = s_begin + a.steps_per_split;
+  if (s_end > total_steps) s_end = total_steps;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (s_begin < s_end) {
+    stage(a.A, a.lda, a.R, s_begin * TR, m0, lds, wave, lane);
+    stage(a.B, a.ldb, a.R, s_begin * TR, n0, lds + HALF, wave, lane);
+  }
+  for (int64_t s = s_begin; s < s_end; ++s) {
+    const int cur = (int)((s - s_begin) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the current slot have landed
+    __syncthreads();                     // ... everyone's have, and everyone is done reading the other slot
+    if (s + 1 < s_end) {
+      unsigned char* nxt = lds + (cur ^ 1) * SLOT;
+      stage(a.A, a.lda, a.R, (s + 1) * TR, m0, nxt, wave, lane);
+      stage(a.B, a.ldb, a.R, (s + 1) * TR, n0, nxt + HALF, wave, lane);
+    }
+    const unsigned char* At = lds + cur * SLOT;
+    const unsigned char* Bt = At + HALF;
+#pragma unroll
+    for (int kk = 0; kk < TR; kk += 32) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = frag(At, 64 * wm + 16 * i, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = frag(Bt, 64 * wn + 16 * j, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // C fragment: lane holds rows 4*(lane/16)+e of the A-side index, column lane%16 of the B-side index
+  float* slab = a.slabs + (int64_t)blockIdx.z * a.Ma * a.Nb;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + 64 * wm + 16 * i + 4 * (lane >> 4) + e;
+        const int n = n0 + 64 * wn + 16 * j + (lane & 15);
+        slab[(int64_t)m * a.Nb + n] = acc[i][j][e];
+      }
+}
+
+__global__ void tn_slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int splits) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
+  for (int z = 1; z < splits; ++z) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + (int64_t)z * n + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] += v[e];
+  }
+  *reinterpret_cast<f32x4*>(out + i) = s;
+}
+
+}  // namespace
+
+// plan shared with dfd_gemm_at_b_workspace (gemm.hip)
+bool dfd_gemm_tn_supported(const void* A, int64_t lda, const void* B, int64_t ldb, int Ma, int Nb) {
+  return Ma % TT == 0 && Nb % TT == 0 && lda % 8 == 0 && ldb % 8 == 0 && dfd_aligned16(A) && dfd_aligned16(B);
+}
+
+int dfd_gemm_tn_splits(int64_t R, int Ma, int Nb) {
+  const int tiles = (Ma / TT) * (Nb / TT);
+  const int64_t steps = (R + TR - 1) / TR;
+  int sp = (512 + tiles - 1) / tiles;  // ~2 workgroups per CU
+  if (sp > steps / 4) sp = (int)(steps / 4 > 0 ? steps / 4 : 1);
+  if (sp > 256) sp = 256;
+  return sp;
+}
+
+int dfd_gemm_tn_launch(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t R, int Ma, int Nb,
+                       float* slabs, hipStream_t st) {
+  TnArgs a;
+  a.A = static_cast<const bf16_t*>(A);
+  a.B = static_cast<const bf16_t*>(B);
+  a.slabs = slabs;
+  a.lda = lda;
+  a.ldb = ldb;
+  a.R = R;
+  a.Ma = Ma;
+  a.Nb = Nb;
+  const int splits = dfd_gemm_tn_splits(R, Ma, Nb);
+  const int64_t steps = (R + TR - 1) / TR;
+  a.steps_per_split = (int)((steps + splits - 1) / splits);
+  const dim3 grid(Nb / TT, Ma / TT, splits);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLOT);
+  hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(256), 2 * SLOT, st, a);
+  DFD_CHECK_LAUNCH("dfd_gemm_at_b(tn)");
+  const int64_t n = (int64_t)Ma * Nb;
+  hipLaunchKernelGGL(tn_slab_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, slabs, C, n, splits);
+  DFD_CHECK_LAUNCH("dfd_gemm_at_b(reduce)");
+  return DFD_OK;
+}

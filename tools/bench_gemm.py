@@ -21,7 +21,9 @@ def main():
     D = 768
     dev = "cuda"
     shapes = [("qkv", 3 * D, D, capi.EPI_QKV_EXPORT, torch.bfloat16), ("out_proj", D, D, capi.EPI_BIAS_RESIDUAL, torch.float32),
-              ("c_fc", 4 * D, D, capi.EPI_BIAS_QUICKGELU, torch.bfloat16), ("c_proj", D, 4 * D, capi.EPI_BIAS_RESIDUAL, torch.float32)]
+              ("c_fc", 4 * D, D, capi.EPI_BIAS_QUICKGELU, torch.bfloat16), ("c_proj", D, 4 * D, capi.EPI_BIAS_RESIDUAL, torch.float32),
+              ("out_proj/d", D, D, capi.EPI_BIAS, torch.bfloat16), ("c_proj/d", D, 4 * D, capi.EPI_BIAS, torch.bfloat16)]
+    Mp = (M + 255) // 256 * 256
     for name, N, K, epi, cdt in shapes:
         a = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
