@@ -123,6 +123,40 @@ def test_gemm_epilogues(capi, M, N, K, dtype):
         assert_close(cf, ref, 1e-4, 1e-5, "bf16->f32")
 
 
+@pytest.mark.parametrize("M,N", [(300 * 256 + 77, 256), (131 * 256 + 5, 768), (94560, 768)])
+def test_gemm_large_m(capi, M, N):
+    """Large-M bf16 GEMMs on the tuned 256x256 kernel (more tiles than CUs, ragged last row tile):
+    checked on a sample of rows plus the whole tail region, every epilogue with a bf16 store."""
+    K = 128
+    g = torch.Generator(device="cuda").manual_seed(M)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    rows = torch.cat([torch.randint(0, M, (4096,), device="cuda", generator=g), torch.arange(M - 70000 if M > 70000 else 0, M, device="cuda")])
+    ref = a[rows].float() @ w.float().T + bias
+    c = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    capi.gemm(a, w, c, bias, capi.EPI_BIAS)
+    assert torch.isfinite(c.float()).all(), "a tile was not written"
+    assert_close(c[rows], ref, 1e-4, 2 ** -8, "bias")
+    capi.gemm(a, w, c, bias, capi.EPI_BIAS_QUICKGELU)
+    assert_close(c[rows], ref * torch.sigmoid(1.702 * ref), 1e-4, 2 ** -8, "quickgelu")
+    if N % 768 == 0:  # QKV export epilogue with both passes on the K / V column tiles
+        tokens, T = 197, 3
+        Mq = M // tokens * tokens
+        D = N // 3
+        tpos = torch.randn(T, D, device="cuda", generator=g)
+        ke = torch.full((Mq // tokens * (tokens - 1), D), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ve = torch.full_like(ke, float("nan"))
+        cq = torch.full((Mq, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        capi.gemm(a[:Mq], w, cq, bias, capi.EPI_QKV_EXPORT, pos=tpos, k_export=ke, v_export=ve, tokens=tokens, frames_per_clip=T)
+        full = a[:Mq].float() @ w.float().T + bias
+        assert_close(cq, full, 1e-4, 2 ** -8, "qkv")
+        fv = full.view(Mq // tokens, tokens, 3, D)
+        pos_f = tpos[torch.arange(Mq // tokens, device="cuda") % T].view(-1, 1, D)
+        assert_close(ke.view(-1, tokens - 1, D), fv[:, 1:, 1] + pos_f, 1e-4, 2 ** -8, "k export")
+        assert_close(ve.view(-1, tokens - 1, D), fv[:, 1:, 2] + pos_f, 1e-4, 2 ** -8, "v export")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_qkv_export_layout(capi, dtype):
     """K/V column blocks land in [frames*P, D] with the CLS row dropped and pos[frame % T] added."""
