@@ -261,8 +261,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
         for (int j = 0; j < 4; ++j) {
           f32x4 v = acc[i][j] + b4[j];
           if constexpr (EPI == DFD_EPI_BIAS_QUICKGELU) {
+            // v * sigmoid(1.702 v) = v / (1 + 2^(-1.702*log2(e)*v)): the epilogue of this shape is VALU-bound
+            // (two waves per SIMD, no MFMA left to hide behind), so the scale constants are folded into
+            // one packed multiply and everything but v_exp_f32 / v_rcp_f32 stays in packed f32 ops
+            float cgelu = -2.45546696f;  // -1.702 * log2(e); opaque + in an SGPR so that the multiply packs
+            asm volatile("" : "+s"(cgelu));
+            const f32x4 t = v * cgelu;
+            f32x4 d;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+            for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_exp2f(t[e]);
+            d = d + 1.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_rcpf(d[e]);
+            v = v * d;
           }
           if (pass == 1) v += p4[j];
           bf16x4 o;
