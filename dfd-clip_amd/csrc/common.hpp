@@ -57,5 +57,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// u * sigmoid(1.702 u); v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE division sequence
-__device__ __forceinline__ float quick_gelu(float u) { return u * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u)); }
+// u * sigmoid(1.702 u) = u / (1 + 2^(-1.702*log2(e)*u)); v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an
+// IEEE division sequence.  Every kernel uses exactly this operation order (gemm256.hip spells it out in
+// packed form), so the tuned and the general GEMM agree bit for bit.
+#define DFD_QUICKGELU_SCALE (-2.45546696f)
+__device__ __forceinline__ float quick_gelu(float u) {
+  return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * DFD_QUICKGELU_SCALE));
+}

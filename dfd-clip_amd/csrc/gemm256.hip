@@ -264,7 +264,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
             // v * sigmoid(1.702 v) = v / (1 + 2^(-1.702*log2(e)*v)): the epilogue of this shape is VALU-bound
             // (two waves per SIMD, no MFMA left to hide behind), so the scale constants are folded into
             // one packed multiply and everything but v_exp_f32 / v_rcp_f32 stays in packed f32 ops
-            float cgelu = -2.45546696f;  // -1.702 * log2(e); opaque + in an SGPR so that the multiply packs
+            float cgelu = DFD_QUICKGELU_SCALE;  // -1.702 * log2(e); opaque + in an SGPR so that the multiply packs
             asm volatile("" : "+s"(cgelu));
             const f32x4 t = v * cgelu;
             f32x4 d;

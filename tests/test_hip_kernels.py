@@ -181,7 +181,7 @@ def test_gemm_qkv_export_layout(capi, dtype):
     assert torch.equal(c, c2)
 
 
-@pytest.mark.parametrize("n,tokens,heads", [(2, 5, 2), (3, 197, 4), (1, 257, 2), (2, 50, 12)])
+@pytest.mark.parametrize("n,tokens,heads", [(2, 5, 2), (3, 197, 4), (1, 257, 2), (2, 50, 12), (64, 197, 12), (45, 200, 12)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_encoder_attention(capi, n, tokens, heads, dtype):
     D = heads * 64
