@@ -109,7 +109,9 @@ def _check(rc, what):
 
 
 def _stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    # torch's current stream on the current device, as a raw hipStream_t: ~0.3 us, where
+    # torch.cuda.current_stream().cuda_stream costs ~8 us (700+ launches per train step)
+    return c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _ptr(t):

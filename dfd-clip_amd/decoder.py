@@ -82,6 +82,7 @@ class Decoder(nn.Module):
                 setattr(self, name, nn.Parameter(scale * torch.randn(width, od)))
             self.task_projections.append([getattr(self, name) for name in names])
         self._wt_cache = {}  # name -> (parameter version, transposed f32 copy) for the row-streaming linear kernel
+        self._param_list = None
         # decoder blocks start from the encoder layer they read (models.py:226-229)
         for b, l in enumerate(self.layer_indices):
             src, dst = enc.transformer.resblocks[l], self.transformer.resblocks[b]
@@ -159,8 +160,10 @@ class Decoder(nn.Module):
         """-> (raw logits list, video_feature, normalised logits list).  With grad enabled and any
         trainable parameter, goes through `_DecoderFn` so `loss.backward()` reaches the parameters."""
         k_all, v_all, mask, B, T, P = self._unpack(kvs, m)
-        names = [n for n, p in self.named_parameters()]
-        params = [p for n, p in self.named_parameters()]
+        if self._param_list is None:  # the module tree is static: walk it once, not every step
+            self._param_list = list(self.named_parameters())
+        names = [n for n, p in self._param_list]
+        params = [p for n, p in self._param_list]
         if torch.is_grad_enabled() and (any(p.requires_grad for p in params) or k_all.requires_grad):
             out = _DecoderFn.apply(self, k_all, v_all, mask, (B, T, P), names, *params)
             n = len(self.out_dims)
