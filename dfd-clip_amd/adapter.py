@@ -1,7 +1,8 @@
 """CompInvAdapter on HIP kernels (reference `src/models.py:783-940`).
 
 Per selected layer and per tensor (k, v): a residual bottleneck
-    kv <- kv + Linear_{x->D}( GELU( LayerNorm( Linear_{D->x}(kv) ) ) )
+    kv <- kv + Linear_{x->D}( GELU( LayerNorm( Linear_{D->x}(kv) ) ) )        structs 768-x-768-{nln, ln, z0}
+    kv <- kv + Linear_{x->D}( LayerNorm( GELU( Linear_{D->x}(kv) ) ) )        structs 768-x-768, legacy-768-x-768
 applied to the exported K/V (CLS row dropped) BEFORE the decoder adds its temporal positional
 embedding.  Parameter names follow the reference's `nn.Sequential` indices
 (`l{i}_{k|v}.0.weight`, `.1.weight`, `.1.bias`, `.4.weight`), so reference checkpoints load.
@@ -26,7 +27,11 @@ from torch import nn
 
 from . import capi
 
-_SUPPORTED = ("768-x-768-nln", "768-x-768-ln", "768-x-768-z0")
+# struct -> (index of the LayerNorm and of the output Linear inside the reference's nn.Sequential, kernel mode:
+# 0 = GELU(LN_row(a)), 1 = GELU(LN_joint(a)), 2 = LN_row(GELU(a)))   (reference models.py:795-875)
+_STRUCTS = {"768-x-768-nln": (1, 4, 1), "768-x-768-ln": (1, 4, 0), "768-x-768-z0": (1, 4, 0),
+            "768-x-768": (2, 4, 2), "legacy-768-x-768": (2, 3, 2)}
+_SUPPORTED = tuple(_STRUCTS)
 
 
 class CompInvAdapter(nn.Module):
@@ -38,6 +43,7 @@ class CompInvAdapter(nn.Module):
         self.struct = config.adapter.struct.type
         if self.struct not in _SUPPORTED:
             raise NotImplementedError(f"adapter struct {self.struct} is not built (supported: {_SUPPORTED})")
+        self.ln_idx, self.out_idx, self.mode = _STRUCTS[self.struct]
         self.inner = int(config.adapter.struct.x)
         self.width = width
         self.residual = True
@@ -45,9 +51,17 @@ class CompInvAdapter(nn.Module):
         for i in range(self.n_layers):
             for j in ("k", "v"):
                 ln_shape = (self.patches, self.inner) if self.struct.endswith("nln") else self.inner
-                seq = nn.Sequential(nn.Linear(width, self.inner, bias=False), nn.LayerNorm(ln_shape), nn.GELU(),
-                                    nn.Dropout(config.dropout / 10), nn.Linear(self.inner, width, bias=False),
-                                    nn.Dropout(config.dropout))
+                if self.struct == "768-x-768":
+                    seq = nn.Sequential(nn.Linear(width, self.inner, bias=False), nn.GELU(), nn.LayerNorm(self.inner),
+                                        nn.Dropout(config.dropout / 5), nn.Linear(self.inner, width, bias=False),
+                                        nn.Dropout(config.dropout))
+                elif self.struct == "legacy-768-x-768":
+                    seq = nn.Sequential(nn.Linear(width, self.inner, bias=False), nn.GELU(), nn.LayerNorm(self.inner),
+                                        nn.Linear(self.inner, width, bias=False), nn.Dropout(config.dropout))
+                else:
+                    seq = nn.Sequential(nn.Linear(width, self.inner, bias=False), nn.LayerNorm(ln_shape), nn.GELU(),
+                                        nn.Dropout(config.dropout / 10), nn.Linear(self.inner, width, bias=False),
+                                        nn.Dropout(config.dropout))
                 if self.struct.endswith("z0"):  # starts as the identity map (models.py:867-869)
                     seq[1].weight.data.zero_()
                     seq[4].weight.data.zero_()
@@ -71,8 +85,9 @@ class CompInvAdapter(nn.Module):
             for i in range(self.n_layers):
                 for j in ("k", "v"):
                     seq = getattr(self, f"l{i}_{j}")
-                    w[(i, j)] = (seq[0].weight.detach().to(act).contiguous(), seq[1].weight.detach().float().contiguous(),
-                                 seq[1].bias.detach().float().contiguous(), seq[4].weight.detach().to(act).contiguous())
+                    ln, out = seq[self.ln_idx], seq[self.out_idx]
+                    w[(i, j)] = (seq[0].weight.detach().to(act).contiguous(), ln.weight.detach().float().contiguous(),
+                                 ln.bias.detach().float().contiguous(), out.weight.detach().to(act).contiguous())
             self._prep = (key, w)
         return self._prep[1]
 
@@ -90,8 +105,9 @@ class CompInvAdapter(nn.Module):
         for i in range(self.n_layers):
             for j in ("k", "v"):
                 pre = f"l{i}_{j}."
-                out[(i, j)] = (w[pre + "0.weight"].to(act).contiguous(), w[pre + "1.weight"].float().contiguous(),
-                               w[pre + "1.bias"].float().contiguous(), w[pre + "4.weight"].to(act).contiguous())
+                out[(i, j)] = (w[pre + "0.weight"].to(act).contiguous(), w[pre + f"{self.ln_idx}.weight"].float().contiguous(),
+                               w[pre + f"{self.ln_idx}.bias"].float().contiguous(),
+                               w[pre + f"{self.out_idx}.weight"].to(act).contiguous())
         return out
 
     def _forward_train(self, w, k_raw, v_raw, num_frames, temporal_pos):
@@ -100,9 +116,11 @@ class CompInvAdapter(nn.Module):
         L, rows, D = k_raw.shape
         P, x = self.patches, self.inner
         frames = rows // P
-        joint = self.struct.endswith("nln")
+        joint = self.mode
         k_out, v_out = torch.empty_like(k_raw), torch.empty_like(v_raw)
-        a1_all = torch.empty(L, 2, rows, x, device=k_raw.device, dtype=act)
+        # GELU-first structs keep the projection output in f32 (LayerNorm after the non-linearity amplifies
+        # the rounding of its input ~4x more than the other order)
+        a1_all = torch.empty(L, 2, rows, x, device=k_raw.device, dtype=torch.float32 if self.mode == 2 else act)
         a2 = torch.empty(rows, x, device=k_raw.device, dtype=act)
         for i in range(L):
             for jj, (j, src, dst) in enumerate((("k", k_raw, k_out), ("v", v_raw, v_out))):
@@ -119,7 +137,7 @@ class CompInvAdapter(nn.Module):
         L, rows, D = k_raw.shape
         P, x = self.patches, self.inner
         frames = rows // P
-        joint = self.struct.endswith("nln")
+        joint = self.mode
         dev = k_raw.device
         f32 = dict(device=dev, dtype=torch.float32)
         a2 = torch.empty(rows, x, device=dev, dtype=act)
@@ -138,14 +156,14 @@ class CompInvAdapter(nn.Module):
                 capi.adapter_norm_gelu(a1, a2, lw, lb, frames, P, x, joint)
                 dw4 = torch.empty(D, x, **f32)
                 capi.gemm_at_b(d_o, a2, dw4, ws_ab)
-                w4t = w[pre + "4.weight"].float().t().contiguous().to(act)  # [x, D]: dA2 = dOut @ W4 as A @ (W4^T)^T
+                w4t = w[pre + f"{self.out_idx}.weight"].float().t().contiguous().to(act)  # [x, D]: dA2 = dOut @ W4 as A @ (W4^T)^T
                 capi.gemm(d_o, w4t, da2, None, capi.EPI_BIAS)
                 dlw, dlb = torch.empty_like(lw), torch.empty_like(lb)
                 capi.adapter_norm_gelu_bwd(a1, da2, da1, lw, lb, dlw, dlb, ws_ln, frames, P, x, joint)
                 dw0 = torch.empty(x, D, **f32)
                 capi.gemm_at_b(da1, src[i], dw0, ws_ab)
-                grads[pre + "0.weight"], grads[pre + "4.weight"] = dw0, dw4
-                grads[pre + "1.weight"], grads[pre + "1.bias"] = dlw, dlb
+                grads[pre + "0.weight"], grads[pre + f"{self.out_idx}.weight"] = dw0, dw4
+                grads[pre + f"{self.ln_idx}.weight"], grads[pre + f"{self.ln_idx}.bias"] = dlw, dlb
         return grads
 
     @torch.no_grad()
@@ -159,14 +177,15 @@ class CompInvAdapter(nn.Module):
         L, rows, D = k_all.shape
         P, x = self.patches, self.inner
         frames = rows // P
-        a1 = torch.empty(rows, x, device=k_all.device, dtype=act)
-        joint = self.struct.endswith("nln")
+        a1 = torch.empty(rows, x, device=k_all.device, dtype=torch.float32 if self.mode == 2 else act)
+        a2 = torch.empty(rows, x, device=k_all.device, dtype=act) if self.mode == 2 else a1
+        joint = self.mode
         for i in range(L):
             for j, t in (("k", k_all), ("v", v_all)):
                 w0, lw, lb, w4 = w[(i, j)]
                 capi.gemm(t[i], w0, a1, None, capi.EPI_BIAS)
-                capi.adapter_norm_gelu(a1, a1, lw, lb, frames, P, x, joint)
-                capi.gemm(a1, w4, t[i], None, capi.EPI_RESIDUAL_POS, pos=temporal_pos, tokens=P + 1, frames_per_clip=num_frames)
+                capi.adapter_norm_gelu(a1, a2, lw, lb, frames, P, x, joint)
+                capi.gemm(a2, w4, t[i], None, capi.EPI_RESIDUAL_POS, pos=temporal_pos, tokens=P + 1, frames_per_clip=num_frames)
         return k_all, v_all
 
 

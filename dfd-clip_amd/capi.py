@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT, EPI_RESIDUAL_POS = range(6)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -45,7 +45,8 @@ SIGNATURES = {
                          POINTER(GemmExtra), c_int64, c_int, c_int, c_void_p]),
     "dfd_gemm_at_b_workspace": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "dfd_gemm_at_b": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
-    "dfd_adapter_norm_gelu": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "dfd_adapter_norm_gelu": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                      c_void_p]),
     "dfd_attention_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dfd_linear_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "dfd_linear_rows_t_workspace": (c_size_t, [c_int, c_int, c_int]),
@@ -63,7 +64,7 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p]),
     "dfd_adapter_norm_gelu_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "dfd_adapter_norm_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "dfd_adapter_norm_gelu_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dfd_linear_rows_bwd_weight": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dfd_transpose_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -245,11 +246,13 @@ def gemm_at_b(a, b, c, workspace):
 
 
 def adapter_norm_gelu(a, y, weight, bias, frames, patches, x, joint, eps=1e-5):
-    """y = GELU(LayerNorm(a)) on [frames, patches, x]; joint: statistics over (patches, x), else per row."""
+    """y = GELU(LayerNorm(a)) on [frames, patches, x]; mode `joint`: 0 per row, 1 statistics over (patches, x),
+    2 = LayerNorm(GELU(a)) per row.  a may be f32 with a bf16 y."""
     _dev(a, y, weight, bias)
-    assert a.dtype == y.dtype and a.is_contiguous() and y.is_contiguous() and weight.is_contiguous() and bias.is_contiguous()
-    _check(load_library().dfd_adapter_norm_gelu(_ptr(a), _ptr(y), _DTYPE[a.dtype], _ptr(weight), _ptr(bias), frames, patches, x,
-                                                int(joint), eps, _stream()), "dfd_adapter_norm_gelu")
+    assert (a.dtype == y.dtype or a.dtype == torch.float32) and a.is_contiguous() and y.is_contiguous()
+    assert weight.is_contiguous() and bias.is_contiguous()
+    _check(load_library().dfd_adapter_norm_gelu(_ptr(a), _DTYPE[a.dtype], _ptr(y), _DTYPE[y.dtype], _ptr(weight), _ptr(bias), frames,
+                                                patches, x, int(joint), eps, _stream()), "dfd_adapter_norm_gelu")
     return y
 
 
@@ -259,8 +262,9 @@ def adapter_norm_gelu_bwd_workspace_bytes(frames, patches, x, joint):
 
 def adapter_norm_gelu_bwd(a, dy, da, weight, bias, dweight, dbias, workspace, frames, patches, x, joint, eps=1e-5):
     _dev(a, dy, da, weight, bias, dweight, dbias, workspace)
-    assert a.dtype == dy.dtype == da.dtype and a.is_contiguous() and dy.is_contiguous() and da.is_contiguous()
-    _check(load_library().dfd_adapter_norm_gelu_bwd(_ptr(a), _ptr(dy), _ptr(da), _DTYPE[a.dtype], _ptr(weight), _ptr(bias),
+    assert dy.dtype == da.dtype and (a.dtype == dy.dtype or a.dtype == torch.float32)
+    assert a.is_contiguous() and dy.is_contiguous() and da.is_contiguous()
+    _check(load_library().dfd_adapter_norm_gelu_bwd(_ptr(a), _DTYPE[a.dtype], _ptr(dy), _ptr(da), _DTYPE[dy.dtype], _ptr(weight), _ptr(bias),
                                                     _ptr(dweight), _ptr(dbias), _ptr(workspace), frames, patches, x, int(joint),
                                                     eps, _stream()), "dfd_adapter_norm_gelu_bwd")
     return da

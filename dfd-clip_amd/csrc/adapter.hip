@@ -12,13 +12,13 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 template <typename T> __device__ __forceinline__ float ld(const T* p) { return to_f32(*p); }
 
 // one workgroup per frame (joint) — slab = patches * x elements
-template <typename T>
-__global__ __launch_bounds__(1024) void adapter_nln_kernel(const T* __restrict__ a, T* __restrict__ y,
+template <typename TA, typename T>
+__global__ __launch_bounds__(1024) void adapter_nln_kernel(const TA* __restrict__ a, T* __restrict__ y,
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            int slab, float eps) {
   __shared__ float sc[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const T* ap = a + (int64_t)blockIdx.x * slab;
+  const TA* ap = a + (int64_t)blockIdx.x * slab;
   T* yp = y + (int64_t)blockIdx.x * slab;
   auto block_sum = [&](float v) {
     v = wave_sum(v);
@@ -39,21 +39,27 @@ __global__ __launch_bounds__(1024) void adapter_nln_kernel(const T* __restrict__
 }
 
 // one wave per row of x
-template <typename T>
-__global__ __launch_bounds__(256) void adapter_ln_kernel(const T* __restrict__ a, T* __restrict__ y, const float* __restrict__ w,
-                                                         const float* __restrict__ b, int64_t rows, int x, float eps) {
+template <typename TA, typename T>
+__global__ __launch_bounds__(256) void adapter_ln_kernel(const TA* __restrict__ a, T* __restrict__ y, const float* __restrict__ w,
+                                                         const float* __restrict__ b, int64_t rows, int x, float eps,
+                                                         int gelu_first) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const T* ap = a + row * x;
+  const TA* ap = a + row * x;
   T* yp = y + row * x;
+  // gelu_first ("768-x-768" / "legacy-768-x-768", models.py:795-821): y = LayerNorm(GELU(a)); else GELU(LayerNorm(a))
+  auto in = [&](int i) { const float v = ld(ap + i); return gelu_first ? gelu_erf(v) : v; };
   float s = 0.f;
-  for (int i = lane; i < x; i += 64) s += ld(ap + i);
+  for (int i = lane; i < x; i += 64) s += in(i);
   const float mean = wave_sum(s) / (float)x;
   float q = 0.f;
-  for (int i = lane; i < x; i += 64) { const float d = ld(ap + i) - mean; q += d * d; }
+  for (int i = lane; i < x; i += 64) { const float d = in(i) - mean; q += d * d; }
   const float rstd = rsqrtf(wave_sum(q) / (float)x + eps);
-  for (int i = lane; i < x; i += 64) yp[i] = from_f32<T>(gelu_erf((ld(ap + i) - mean) * rstd * w[i] + b[i]));
+  for (int i = lane; i < x; i += 64) {
+    const float z = (in(i) - mean) * rstd * w[i] + b[i];
+    yp[i] = from_f32<T>(gelu_first ? z : gelu_erf(z));
+  }
 }
 
 __device__ __forceinline__ float gelu_erf_grad(float z) {
@@ -62,14 +68,14 @@ __device__ __forceinline__ float gelu_erf_grad(float z) {
 
 // ---- backward, pass 1: one workgroup per normalisation group (frame slab for "nln", row for "ln") -------
 // da = rstd * (g - mean(g) - nhat * mean(g * nhat)),  g = dy * gelu'(nhat*w + b) * w;  saves (mean, rstd)
-template <typename T>
-__global__ __launch_bounds__(1024) void adapter_bwd_group_kernel(const T* __restrict__ a, const T* __restrict__ dy,
+template <typename TA, typename T>
+__global__ __launch_bounds__(1024) void adapter_bwd_group_kernel(const TA* __restrict__ a, const T* __restrict__ dy,
                                                                  T* __restrict__ da, const float* __restrict__ w,
                                                                  const float* __restrict__ b, float* __restrict__ stats,
-                                                                 int group, int affine_period, float eps) {
+                                                                 int group, int affine_period, float eps, int gelu_first) {
   __shared__ float sc[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const T* ap = a + (int64_t)blockIdx.x * group;
+  const TA* ap = a + (int64_t)blockIdx.x * group;
   const T* dp = dy + (int64_t)blockIdx.x * group;
   T* op = da + (int64_t)blockIdx.x * group;
   auto block_sum = [&](float v) {
@@ -81,37 +87,41 @@ __global__ __launch_bounds__(1024) void adapter_bwd_group_kernel(const T* __rest
     for (int i = 0; i < nw; ++i) t += sc[i];
     return t;
   };
+  // gelu_first: the normalised quantity is u = GELU(a); dL/du = LN backward of dy*w, dL/da = dL/du * GELU'(a)
+  auto in = [&](int i) { const float v = ld(ap + i); return gelu_first ? gelu_erf(v) : v; };
   float s = 0.f;
-  for (int i = tid; i < group; i += blockDim.x) s += ld(ap + i);
+  for (int i = tid; i < group; i += blockDim.x) s += in(i);
   const float mean = block_sum(s) / (float)group;
   float q = 0.f;
-  for (int i = tid; i < group; i += blockDim.x) { const float d = ld(ap + i) - mean; q += d * d; }
+  for (int i = tid; i < group; i += blockDim.x) { const float d = in(i) - mean; q += d * d; }
   const float rstd = rsqrtf(block_sum(q) / (float)group + eps);
   float s1 = 0.f, s2 = 0.f;
   for (int i = tid; i < group; i += blockDim.x) {
     const int e = i % affine_period;
-    const float nh = (ld(ap + i) - mean) * rstd;
-    const float g = ld(dp + i) * gelu_erf_grad(nh * w[e] + b[e]) * w[e];
+    const float nh = (in(i) - mean) * rstd;
+    const float g = ld(dp + i) * (gelu_first ? 1.0f : gelu_erf_grad(nh * w[e] + b[e])) * w[e];
     s1 += g;
     s2 += g * nh;
   }
   const float m1 = block_sum(s1) / (float)group, m2 = block_sum(s2) / (float)group;
   for (int i = tid; i < group; i += blockDim.x) {
     const int e = i % affine_period;
-    const float nh = (ld(ap + i) - mean) * rstd;
-    const float g = ld(dp + i) * gelu_erf_grad(nh * w[e] + b[e]) * w[e];
-    op[i] = from_f32<T>(rstd * (g - m1 - nh * m2));
+    const float nh = (in(i) - mean) * rstd;
+    const float g = ld(dp + i) * (gelu_first ? 1.0f : gelu_erf_grad(nh * w[e] + b[e])) * w[e];
+    const float du = rstd * (g - m1 - nh * m2);
+    op[i] = from_f32<T>(gelu_first ? du * gelu_erf_grad(ld(ap + i)) : du);
   }
   if (tid == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
 }
 
 // ---- backward, pass 2: affine gradients.  Thread per affine element e, block-row per chunk of groups;
 // partial sums go to slab blockIdx.y and are added in fixed order by adapter_bwd_affine_reduce_kernel.
-template <typename T>
-__global__ __launch_bounds__(256) void adapter_bwd_affine_kernel(const T* __restrict__ a, const T* __restrict__ dy,
+template <typename TA, typename T>
+__global__ __launch_bounds__(256) void adapter_bwd_affine_kernel(const TA* __restrict__ a, const T* __restrict__ dy,
                                                                  const float* __restrict__ w, const float* __restrict__ b,
                                                                  const float* __restrict__ stats, float* __restrict__ part,
-                                                                 int64_t groups, int group, int affine, int groups_per_slab) {
+                                                                 int64_t groups, int group, int affine, int groups_per_slab,
+                                                                 int gelu_first) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= affine) return;
   const int reps = group / affine;  // rows of an affine period inside one group (1 for nln, 1 for ln)
@@ -123,8 +133,9 @@ __global__ __launch_bounds__(256) void adapter_bwd_affine_kernel(const T* __rest
     const float mean = stats[2 * gi], rstd = stats[2 * gi + 1];
     for (int r = 0; r < reps; ++r) {
       const int64_t idx = gi * group + (int64_t)r * affine + e;
-      const float nh = (ld(a + idx) - mean) * rstd;
-      const float dz = ld(dy + idx) * gelu_erf_grad(nh * we + be);
+      const float av = ld(a + idx);
+      const float nh = ((gelu_first ? gelu_erf(av) : av) - mean) * rstd;
+      const float dz = ld(dy + idx) * (gelu_first ? 1.0f : gelu_erf_grad(nh * we + be));
       dw = fmaf(dz, nh, dw);
       db += dz;
     }
@@ -156,19 +167,24 @@ int affine_slabs(int64_t groups, int affine) {
 
 extern "C" size_t dfd_adapter_norm_gelu_bwd_workspace(int frames, int patches, int x, int joint) {
   if (frames <= 0 || patches <= 0 || x <= 0) return 0;
-  const int64_t groups = joint ? frames : (int64_t)frames * patches;
-  const int affine = joint ? patches * x : x;
+  const bool jt = joint == 1;
+  const int64_t groups = jt ? frames : (int64_t)frames * patches;
+  const int affine = jt ? patches * x : x;
   return (size_t)groups * 2 * sizeof(float) + (size_t)affine_slabs(groups, affine) * 2 * affine * sizeof(float);
 }
 
-extern "C" int dfd_adapter_norm_gelu_bwd(const void* a, const void* dy, void* da, int dtype, const float* weight,
+extern "C" int dfd_adapter_norm_gelu_bwd(const void* a, int a_dtype, const void* dy, void* da, int dtype, const float* weight,
                                          const float* bias, float* dweight, float* dbias, void* workspace, int frames,
                                          int patches, int x, int joint, float eps, void* stream) {
   DFD_REQUIRE(a && dy && da && weight && bias && dweight && dbias && workspace, "dfd_adapter_norm_gelu_bwd: null pointer");
   DFD_REQUIRE(frames > 0 && patches > 0 && x > 0, "dfd_adapter_norm_gelu_bwd: bad shape");
   DFD_REQUIRE(da != dy && da != a, "dfd_adapter_norm_gelu_bwd: da must not alias dy or a (both are re-read by the affine pass)");
   DFD_REQUIRE(dtype == DFD_F32 || dtype == DFD_BF16, "dfd_adapter_norm_gelu_bwd: dtype=%d", dtype);
+  DFD_REQUIRE(a_dtype == dtype || a_dtype == DFD_F32, "dfd_adapter_norm_gelu_bwd: a_dtype=%d must be dtype or f32", a_dtype);
+  DFD_REQUIRE(joint >= 0 && joint <= 2, "dfd_adapter_norm_gelu_bwd: mode=%d", joint);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int gelu_first = joint == 2;
+  joint = joint == 1;
   const int64_t groups = joint ? frames : (int64_t)frames * patches;
   const int group = joint ? patches * x : x;
   const int affine = group;
@@ -177,42 +193,48 @@ extern "C" int dfd_adapter_norm_gelu_bwd(const void* a, const void* dy, void* da
   const int slabs = affine_slabs(groups, affine);
   const int gps = (int)((groups + slabs - 1) / slabs);
   const int threads = joint ? 1024 : 64;
-#define ADP_LAUNCH(T)                                                                                                     \
-  hipLaunchKernelGGL((adapter_bwd_group_kernel<T>), dim3((unsigned)groups), dim3(threads), 0, st, static_cast<const T*>(a),  \
-                     static_cast<const T*>(dy), static_cast<T*>(da), weight, bias, stats, group, affine, eps);             \
-  hipLaunchKernelGGL((adapter_bwd_affine_kernel<T>), dim3((affine + 255) / 256, slabs), dim3(256), 0, st,                    \
-                     static_cast<const T*>(a), static_cast<const T*>(dy), weight, bias, stats, part, groups, group, affine, gps);
-  if (dtype == DFD_F32) { ADP_LAUNCH(float) } else { ADP_LAUNCH(bf16_t) }
+#define ADP_LAUNCH(TA, T)                                                                                                 \
+  hipLaunchKernelGGL((adapter_bwd_group_kernel<TA, T>), dim3((unsigned)groups), dim3(threads), 0, st,                        \
+                     static_cast<const TA*>(a), static_cast<const T*>(dy), static_cast<T*>(da), weight, bias, stats, group, \
+                     affine, eps, gelu_first);                                                                            \
+  hipLaunchKernelGGL((adapter_bwd_affine_kernel<TA, T>), dim3((affine + 255) / 256, slabs), dim3(256), 0, st,                \
+                     static_cast<const TA*>(a), static_cast<const T*>(dy), weight, bias, stats, part, groups, group, affine, \
+                     gps, gelu_first);
+  if (dtype == DFD_F32) { ADP_LAUNCH(float, float) }
+  else if (a_dtype == DFD_F32) { ADP_LAUNCH(float, bf16_t) }
+  else { ADP_LAUNCH(bf16_t, bf16_t) }
 #undef ADP_LAUNCH
   hipLaunchKernelGGL(adapter_bwd_affine_reduce_kernel, dim3((affine + 255) / 256), dim3(256), 0, st, part, dweight, dbias, affine, slabs);
   DFD_CHECK_LAUNCH("dfd_adapter_norm_gelu_bwd");
   return DFD_OK;
 }
 
-extern "C" int dfd_adapter_norm_gelu(const void* a, void* y, int dtype, const float* weight, const float* bias, int frames,
+extern "C" int dfd_adapter_norm_gelu(const void* a, int a_dtype, void* y, int dtype, const float* weight, const float* bias, int frames,
                                      int patches, int x, int joint, float eps, void* stream) {
   DFD_REQUIRE(a && y && weight && bias, "dfd_adapter_norm_gelu: null pointer");
   DFD_REQUIRE(frames >= 0 && patches > 0 && x > 0, "dfd_adapter_norm_gelu: bad shape");
   DFD_REQUIRE(dtype == DFD_F32 || dtype == DFD_BF16, "dfd_adapter_norm_gelu: dtype=%d", dtype);
+  DFD_REQUIRE(a_dtype == dtype || a_dtype == DFD_F32, "dfd_adapter_norm_gelu: a_dtype=%d must be dtype or f32", a_dtype);
+  DFD_REQUIRE(a_dtype == dtype || a != y, "dfd_adapter_norm_gelu: in place needs one dtype");
+  DFD_REQUIRE(joint >= 0 && joint <= 2, "dfd_adapter_norm_gelu: mode=%d", joint);
   if (frames == 0) return DFD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (joint) {
-    if (dtype == DFD_F32)
-      hipLaunchKernelGGL((adapter_nln_kernel<float>), dim3(frames), dim3(1024), 0, st, static_cast<const float*>(a),
-                         static_cast<float*>(y), weight, bias, patches * x, eps);
-    else
-      hipLaunchKernelGGL((adapter_nln_kernel<bf16_t>), dim3(frames), dim3(1024), 0, st, static_cast<const bf16_t*>(a),
-                         static_cast<bf16_t*>(y), weight, bias, patches * x, eps);
-  } else {
-    const int64_t rows = (int64_t)frames * patches;
-    const dim3 grid((unsigned)((rows + 3) / 4));
-    if (dtype == DFD_F32)
-      hipLaunchKernelGGL((adapter_ln_kernel<float>), grid, dim3(256), 0, st, static_cast<const float*>(a), static_cast<float*>(y),
-                         weight, bias, rows, x, eps);
-    else
-      hipLaunchKernelGGL((adapter_ln_kernel<bf16_t>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(a),
-                         static_cast<bf16_t*>(y), weight, bias, rows, x, eps);
-  }
+  const int gelu_first = joint == 2;
+  const int64_t rows = (int64_t)frames * patches;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+#define FWD_LAUNCH(TA, T)                                                                                              \
+  do {                                                                                                                 \
+    if (joint == 1)                                                                                                    \
+      hipLaunchKernelGGL((adapter_nln_kernel<TA, T>), dim3(frames), dim3(1024), 0, st, static_cast<const TA*>(a),        \
+                         static_cast<T*>(y), weight, bias, patches * x, eps);                                          \
+    else                                                                                                               \
+      hipLaunchKernelGGL((adapter_ln_kernel<TA, T>), grid, dim3(256), 0, st, static_cast<const TA*>(a), static_cast<T*>(y), \
+                         weight, bias, rows, x, eps, gelu_first);                                                      \
+  } while (0)
+  if (dtype == DFD_F32) FWD_LAUNCH(float, float);
+  else if (a_dtype == DFD_F32) FWD_LAUNCH(float, bf16_t);
+  else FWD_LAUNCH(bf16_t, bf16_t);
+#undef FWD_LAUNCH
   DFD_CHECK_LAUNCH("dfd_adapter_norm_gelu");
   return DFD_OK;
 }

@@ -112,6 +112,11 @@ def adapter_schema(arch, n_blocks, struct_type, x):
                 s[p + "1.weight"] = (x,)
                 s[p + "1.bias"] = (x,)
                 s[p + "4.weight"] = (width, x)
+            elif struct_type in ("768-x-768", "legacy-768-x-768"):  # Linear, GELU, LayerNorm, [Dropout,] Linear
+                s[p + "0.weight"] = (x, width)
+                s[p + "2.weight"] = (x,)
+                s[p + "2.bias"] = (x,)
+                s[p + ("4.weight" if struct_type == "768-x-768" else "3.weight")] = (width, x)
             else:
                 raise NotImplementedError(struct_type)
     return s
@@ -122,7 +127,8 @@ def _fill(rng, name, shape):
     O(1); LayerNorm gains near 1 and all biases small but non-zero so that every gain/bias
     path is exercised by the parity tests."""
     leaf = name.split(".")[-1]
-    is_ln = ".ln_" in name or name.startswith("ln_") or (name.split(".")[-2:-1] == ["1"])
+    is_ln = ".ln_" in name or name.startswith("ln_") or (name.split(".")[-2:-1] == ["1"]) or \
+        (name.split(".")[-2:-1] == ["2"] and len(shape) == 1)
     if is_ln and leaf == "weight":
         a = 1.0 + 0.05 * rng.standard_normal(shape)
     elif leaf == "bias" or leaf.endswith("in_proj_bias"):

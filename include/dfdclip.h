@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DFD_ABI_VERSION 6
+#define DFD_ABI_VERSION 7
 
 enum { DFD_F32 = 0, DFD_BF16 = 1 };
 
@@ -169,16 +169,20 @@ int dfd_head_fwd(const float* x, int64_t ldx, const float* gamma, const float* b
                  void* stream);
 
 /* CompInvAdapter middle stage (models.py:823-875): y = GELU_erf(LayerNorm(a)) on a [frames, patches, x]
- * tensor in `dtype`.  joint != 0 ("nln"): statistics over the whole (patches, x) slab of a frame, affine
- * weight/bias [patches, x]; joint == 0 ("ln"/"z0"): statistics per row of x, affine [x].  y may alias a. */
-int dfd_adapter_norm_gelu(const void* a, void* y, int dtype, const float* weight, const float* bias, int frames,
+ * tensor in `dtype`.  joint == 1 ("nln"): statistics over the whole (patches, x) slab of a frame, affine
+ * weight/bias [patches, x]; joint == 0 ("ln"/"z0"): statistics per row of x, affine [x]; joint == 2
+ * ("768-x-768" / "legacy-768-x-768", models.py:795-821): y = LayerNorm(GELU(a)) per row of x — the same two
+ * stages in the other order.  `a` is in a_dtype = dtype, or f32 with a bf16 y (the GELU-first structs keep
+ * the projection output in f32: LayerNorm after the non-linearity amplifies its rounding).  y may alias a
+ * when the dtypes agree.  The backward takes the same mode and a_dtype. */
+int dfd_adapter_norm_gelu(const void* a, int a_dtype, void* y, int dtype, const float* weight, const float* bias, int frames,
                           int patches, int x, int joint, float eps, void* stream);
 
 /* Backward of dfd_adapter_norm_gelu: a = the forward's input, dy = dL/dy; writes da = dL/da (same dtype;
  * must NOT alias dy: the affine pass re-reads dy) and the affine gradients dweight / dbias (shapes of weight / bias), summed over frames in
  * a fixed order.  workspace >= dfd_adapter_norm_gelu_bwd_workspace(...) bytes. */
 size_t dfd_adapter_norm_gelu_bwd_workspace(int frames, int patches, int x, int joint);
-int dfd_adapter_norm_gelu_bwd(const void* a, const void* dy, void* da, int dtype, const float* weight, const float* bias,
+int dfd_adapter_norm_gelu_bwd(const void* a, int a_dtype, const void* dy, void* da, int dtype, const float* weight, const float* bias,
                               float* dweight, float* dbias, void* workspace, int frames, int patches, int x, int joint,
                               float eps, void* stream);
 

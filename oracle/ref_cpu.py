@@ -82,9 +82,14 @@ def encoder_forward(w, x, heads, patch, prefix="encoder.", with_out=False, with_
 
 
 def adapter_forward(w, kvs, struct_type, prefix="adapter."):
-    """`CompInvAdapter.forward` in eval mode (reference `src/models.py:930-940`) for the
-    LayerNorm structs (`:823-875`): Linear(D->x, no bias) -> LayerNorm (over (P, x) jointly
-    for `nln`, over x for `ln`/`z0`) -> exact-erf GELU -> Linear(x->D, no bias), residual."""
+    """`CompInvAdapter.forward` in eval mode (reference `src/models.py:930-940`).  LayerNorm-then-GELU
+    structs (`:823-875`): Linear(D->x, no bias) -> LayerNorm (over (P, x) jointly for `nln`, over x
+    for `ln`/`z0`) -> exact-erf GELU -> Linear(x->D, no bias), residual.  GELU-then-LayerNorm structs
+    `768-x-768` (`:795-808`, output Linear at Sequential index 4) and `legacy-768-x-768` (`:809-821`,
+    index 3): Linear -> GELU -> LayerNorm(x) -> Linear, residual."""
+    gelu_first = struct_type in ("768-x-768", "legacy-768-x-768")
+    ln_idx = 2 if gelu_first else 1
+    out_idx = 3 if struct_type == "legacy-768-x-768" else 4
     out = []
     for i, kv in enumerate(kvs):
         new = {}
@@ -93,10 +98,12 @@ def adapter_forward(w, kvs, struct_type, prefix="adapter."):
             b, tt, p, h, d = t.shape
             f = t.reshape(b, tt, p, h * d)
             a = F.linear(f, w[f"{prefix}l{i}_{name}.0.weight"])
-            lw, lb = w[f"{prefix}l{i}_{name}.1.weight"], w[f"{prefix}l{i}_{name}.1.bias"]
-            a = F.layer_norm(a, tuple(lw.shape), lw, lb, 1e-5)
-            a = F.gelu(a)
-            a = F.linear(a, w[f"{prefix}l{i}_{name}.4.weight"])
+            lw, lb = w[f"{prefix}l{i}_{name}.{ln_idx}.weight"], w[f"{prefix}l{i}_{name}.{ln_idx}.bias"]
+            if gelu_first:
+                a = F.layer_norm(F.gelu(a), tuple(lw.shape), lw, lb, 1e-5)
+            else:
+                a = F.gelu(F.layer_norm(a, tuple(lw.shape), lw, lb, 1e-5))
+            a = F.linear(a, w[f"{prefix}l{i}_{name}.{out_idx}.weight"])
             new[name] = t + a.reshape(b, tt, p, h, d)
         out.append(new)
     return out

@@ -18,6 +18,10 @@ CASES = {
                                             adapter__frozen=0, adapter__struct={"type": "768-x-768-nln", "x": 32})),
     "tiny_adapter_ln": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], adapter__type="normal",
                                            adapter__frozen=0, adapter__struct={"type": "768-x-768-ln", "x": 32})),
+    "tiny_adapter_gl": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], adapter__type="normal",
+                                           adapter__frozen=0, adapter__struct={"type": "768-x-768", "x": 32})),
+    "tiny_adapter_legacy": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], adapter__type="normal",
+                                               adapter__frozen=0, adapter__struct={"type": "legacy-768-x-768", "x": 32})),
     "tiny_global": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], op_mode__global_prediction=1)),
     "tiny_attnmode": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], op_mode__attn_mode="frame+temporal")),
     "tiny_nopos": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], op_mode__temporal_position=0)),

@@ -188,7 +188,7 @@ def make_detector(case, precision):
     return det.to("cuda")
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_nopos", "tiny_augq", "tiny_adapter_nln", "tiny_adapter_ln", "small", "small14", "vitb16_cfg1",
+@pytest.mark.parametrize("name", ["tiny", "tiny_nopos", "tiny_augq", "tiny_adapter_nln", "tiny_adapter_ln", "tiny_adapter_gl", "tiny_adapter_legacy", "small", "small14", "vitb16_cfg1",
                                   "tiny_global", "tiny_attnmode"])
 def test_train_step_contract_matches_reference(name):
     """fp32 path: gradients of every decoder parameter after backward(mean loss), then two SGD steps
