@@ -11,6 +11,37 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 
 template <typename T> __device__ __forceinline__ float ld(const T* p) { return to_f32(*p); }
 
+template <typename T> struct Ld8;
+template <> struct Ld8<float> {
+  static __device__ __forceinline__ void load(const float* p, float* o) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+  }
+};
+template <> struct Ld8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float* o) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)a[e];
+  }
+};
+template <typename T> struct St8;
+template <> struct St8<float> {
+  static __device__ __forceinline__ void store(float* p, const float* o) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{o[4], o[5], o[6], o[7]};
+  }
+};
+template <> struct St8<bf16_t> {
+  static __device__ __forceinline__ void store(bf16_t* p, const float* o) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (bf16_t)o[e];
+    *reinterpret_cast<bf16x8*>(p) = r;
+  }
+};
+
 // one workgroup per frame (joint) — slab = patches * x elements
 template <typename TA, typename T>
 __global__ __launch_bounds__(1024) void adapter_nln_kernel(const TA* __restrict__ a, T* __restrict__ y,
@@ -36,6 +67,62 @@ __global__ __launch_bounds__(1024) void adapter_nln_kernel(const TA* __restrict_
   for (int i = tid; i < slab; i += blockDim.x) { const float d = ld(ap + i) - mean; q += d * d; }
   const float rstd = rsqrtf(block_sum(q) / (float)slab + eps);
   for (int i = tid; i < slab; i += blockDim.x) yp[i] = from_f32<T>(gelu_erf((ld(ap + i) - mean) * rstd * w[i] + b[i]));
+}
+
+// Register-resident form of the joint ("nln") kernel: the frame's (patches, x) slab is read ONCE, 8
+// elements (16 bytes of bf16) per load, held in registers across the two statistics passes and the
+// affine + GELU pass.  Needs slab % 8 == 0 and slab <= 1024 * 8 * NCH.
+template <typename TA, typename T, int NCH>
+__global__ __launch_bounds__(1024) void adapter_nln_reg_kernel(const TA* __restrict__ a, T* __restrict__ y,
+                                                               const float* __restrict__ w, const float* __restrict__ b,
+                                                               int slab, float eps) {
+  __shared__ float sc[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const TA* ap = a + (int64_t)blockIdx.x * slab;
+  T* yp = y + (int64_t)blockIdx.x * slab;
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sc[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sc[i];
+    return t;
+  };
+  const int nchunk = slab >> 3;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = tid + c * 1024;
+    if (ch < nchunk) {
+      Ld8<TA>::load(ap + (int64_t)ch * 8, v[c]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[c][e];
+    }
+  }
+  const float mean = block_sum(s) / (float)slab;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    if (tid + c * 1024 < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q += d * d; }
+    }
+  const float rstd = rsqrtf(block_sum(q) / (float)slab + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = tid + c * 1024;
+    if (ch < nchunk) {
+      float ww[8], bb[8], o[8];
+      Ld8<float>::load(w + (int64_t)ch * 8, ww);
+      Ld8<float>::load(b + (int64_t)ch * 8, bb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = gelu_erf((v[c][e] - mean) * rstd * ww[e] + bb[e]);
+      St8<T>::store(yp + (int64_t)ch * 8, o);
+    }
+  }
 }
 
 // one wave per row of x
@@ -110,6 +197,89 @@ __global__ __launch_bounds__(1024) void adapter_bwd_group_kernel(const TA* __res
     const float g = ld(dp + i) * (gelu_first ? 1.0f : gelu_erf_grad(nh * w[e] + b[e])) * w[e];
     const float du = rstd * (g - m1 - nh * m2);
     op[i] = from_f32<T>(gelu_first ? du * gelu_erf_grad(ld(ap + i)) : du);
+  }
+  if (tid == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
+}
+
+// Register-resident form of the group pass for the joint ("nln") mode: `a` is read once with 16-byte
+// loads and kept normalised in registers; dy / weight / bias are streamed twice (second time from L2).
+template <typename TA, typename T, int NCH>
+__global__ __launch_bounds__(1024) void adapter_bwd_group_reg_kernel(const TA* __restrict__ a, const T* __restrict__ dy,
+                                                                     T* __restrict__ da, const float* __restrict__ w,
+                                                                     const float* __restrict__ b, float* __restrict__ stats,
+                                                                     int group, float eps) {
+  __shared__ float sc[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const TA* ap = a + (int64_t)blockIdx.x * group;
+  const T* dp = dy + (int64_t)blockIdx.x * group;
+  T* op = da + (int64_t)blockIdx.x * group;
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sc[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sc[i];
+    return t;
+  };
+  const int nchunk = group >> 3;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = tid + c * 1024;
+    if (ch < nchunk) {
+      Ld8<TA>::load(ap + (int64_t)ch * 8, v[c]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[c][e];
+    }
+  }
+  const float mean = block_sum(s) / (float)group;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    if (tid + c * 1024 < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q += d * d; }
+    }
+  const float rstd = rsqrtf(block_sum(q) / (float)group + eps);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = tid + c * 1024;
+    if (ch < nchunk) {
+      float dd[8], ww[8], bb[8];
+      Ld8<T>::load(dp + (int64_t)ch * 8, dd);
+      Ld8<float>::load(w + (int64_t)ch * 8, ww);
+      Ld8<float>::load(b + (int64_t)ch * 8, bb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float nh = (v[c][e] - mean) * rstd;
+        v[c][e] = nh;  // keep the normalised value
+        const float g = dd[e] * gelu_erf_grad(nh * ww[e] + bb[e]) * ww[e];
+        s1 += g;
+        s2 += g * nh;
+      }
+    }
+  }
+  const float m1 = block_sum(s1) / (float)group, m2 = block_sum(s2) / (float)group;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = tid + c * 1024;
+    if (ch < nchunk) {
+      float dd[8], ww[8], bb[8], o[8];
+      Ld8<T>::load(dp + (int64_t)ch * 8, dd);
+      Ld8<float>::load(w + (int64_t)ch * 8, ww);
+      Ld8<float>::load(b + (int64_t)ch * 8, bb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float nh = v[c][e];
+        const float g = dd[e] * gelu_erf_grad(nh * ww[e] + bb[e]) * ww[e];
+        o[e] = rstd * (g - m1 - nh * m2);
+      }
+      St8<T>::store(op + (int64_t)ch * 8, o);
+    }
   }
   if (tid == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
 }
@@ -193,10 +363,17 @@ extern "C" int dfd_adapter_norm_gelu_bwd(const void* a, int a_dtype, const void*
   const int slabs = affine_slabs(groups, affine);
   const int gps = (int)((groups + slabs - 1) / slabs);
   const int threads = joint ? 1024 : 64;
+  const bool reg_ok = joint && group % 8 == 0 && group <= 1024 * 8 * 7 && dfd_aligned16(a) && dfd_aligned16(dy) &&
+                      dfd_aligned16(da) && dfd_aligned16(weight) && dfd_aligned16(bias);
 #define ADP_LAUNCH(TA, T)                                                                                                 \
-  hipLaunchKernelGGL((adapter_bwd_group_kernel<TA, T>), dim3((unsigned)groups), dim3(threads), 0, st,                        \
-                     static_cast<const TA*>(a), static_cast<const T*>(dy), static_cast<T*>(da), weight, bias, stats, group, \
-                     affine, eps, gelu_first);                                                                            \
+  if (reg_ok)                                                                                                             \
+    hipLaunchKernelGGL((adapter_bwd_group_reg_kernel<TA, T, 7>), dim3((unsigned)groups), dim3(1024), 0, st,                  \
+                       static_cast<const TA*>(a), static_cast<const T*>(dy), static_cast<T*>(da), weight, bias, stats,      \
+                       group, eps);                                                                                       \
+  else                                                                                                                    \
+    hipLaunchKernelGGL((adapter_bwd_group_kernel<TA, T>), dim3((unsigned)groups), dim3(threads), 0, st,                      \
+                       static_cast<const TA*>(a), static_cast<const T*>(dy), static_cast<T*>(da), weight, bias, stats,      \
+                       group, affine, eps, gelu_first);                                                                   \
   hipLaunchKernelGGL((adapter_bwd_affine_kernel<TA, T>), dim3((affine + 255) / 256, slabs), dim3(256), 0, st,                \
                      static_cast<const TA*>(a), static_cast<const T*>(dy), weight, bias, stats, part, groups, group, affine, \
                      gps, gelu_first);
@@ -222,9 +399,16 @@ extern "C" int dfd_adapter_norm_gelu(const void* a, int a_dtype, void* y, int dt
   const int gelu_first = joint == 2;
   const int64_t rows = (int64_t)frames * patches;
   const dim3 grid((unsigned)((rows + 3) / 4));
+  const int slab_all = patches * x;
+  // register-resident slab: 16-byte loads need slab % 8 == 0 and aligned bases; 7 chunks x 1024 threads x 8
+  const bool reg_ok = slab_all % 8 == 0 && slab_all <= 1024 * 8 * 7 && dfd_aligned16(a) && dfd_aligned16(y) &&
+                      dfd_aligned16(weight) && dfd_aligned16(bias);
 #define FWD_LAUNCH(TA, T)                                                                                              \
   do {                                                                                                                 \
-    if (joint == 1)                                                                                                    \
+    if (joint == 1 && reg_ok)                                                                                          \
+      hipLaunchKernelGGL((adapter_nln_reg_kernel<TA, T, 7>), dim3(frames), dim3(1024), 0, st, static_cast<const TA*>(a), \
+                         static_cast<T*>(y), weight, bias, patches * x, eps);                                          \
+    else if (joint == 1)                                                                                               \
       hipLaunchKernelGGL((adapter_nln_kernel<TA, T>), dim3(frames), dim3(1024), 0, st, static_cast<const TA*>(a),        \
                          static_cast<T*>(y), weight, bias, patches * x, eps);                                          \
     else                                                                                                               \
