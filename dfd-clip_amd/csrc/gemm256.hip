@@ -252,8 +252,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
         f32x4 p4[4];
         if (pass == 1) {  // exported copy = f32 value + temporal positional embedding, rounded once
           const int64_t m = m0 + wr * 128 + row;
-          const int64_t frame = (m < a.M ? m : a.M - 1) / a.tokens;
-          const float* pr = a.pos ? a.pos + (frame % a.frames_per_clip) * D + (nb - which * D) + fq * 4 : nullptr;
+          // 32-bit unsigned division (M < 2^31 is checked by the launcher): the 64-bit form costs ~4x the instructions
+          const uint32_t frame = (uint32_t)(m < a.M ? m : a.M - 1) / (uint32_t)a.tokens;
+          const float* pr = a.pos ? a.pos + (int64_t)(frame % (uint32_t)a.frames_per_clip) * D + (nb - which * D) + fq * 4 : nullptr;
 #pragma unroll
           for (int j = 0; j < 4; ++j) p4[j] = pr ? *reinterpret_cast<const f32x4*>(pr + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -293,9 +294,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
           if (pass == 0) {
             *reinterpret_cast<uint4*>(dst + m * a.ldc + nb + c * 8) = d;
           } else {
-            const int64_t frame = m / a.tokens;
-            const int tok = (int)(m - frame * a.tokens);
-            if (tok > 0) *reinterpret_cast<uint4*>(dst + (frame * (a.tokens - 1) + tok - 1) * D + (nb - which * D) + c * 8) = d;
+            const uint32_t frame = (uint32_t)m / (uint32_t)a.tokens;
+            const int tok = (int)((uint32_t)m - frame * (uint32_t)a.tokens);
+            if (tok > 0)
+              *reinterpret_cast<uint4*>(dst + ((int64_t)frame * (a.tokens - 1) + tok - 1) * D + (nb - which * D) + c * 8) = d;
           }
         }
       }
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
           const bf16x8 old = a.residual ? *reinterpret_cast<const bf16x8*>(static_cast<const bf16_t*>(a.residual) + m * a.ldc + nb + c * 8) : *cp;
           f32x4 p0 = f32x4{0.f, 0.f, 0.f, 0.f}, p1 = p0;
           if (a.pos) {
-            const float* pr = a.pos + ((m / rows_per_frame) % a.frames_per_clip) * a.N + nb + c * 8;
+            const float* pr = a.pos + (int64_t)(((uint32_t)m / (uint32_t)rows_per_frame) % (uint32_t)a.frames_per_clip) * a.N + nb + c * 8;
             p0 = *reinterpret_cast<const f32x4*>(pr);
             p1 = *reinterpret_cast<const f32x4*>(pr + 4);
           }
@@ -479,6 +481,7 @@ int DFD_GEMM256_TRY(const GemmArgs& a, int c_dtype, int epi, hipStream_t st) {
   if ((reinterpret_cast<uintptr_t>(a.C) & 15) != 0) return 1;
   if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15) != 0) return 1;
   if ((int64_t)((a.M + TM - 1) / TM) * (a.N / TN) > 0x7fffffff) return 1;
+  if (a.M >= ((int64_t)1 << 31)) return 1;  // the epilogues index rows with 32-bit arithmetic
   switch (epi) {
     case DFD_EPI_BIAS:
       return c_dtype == DFD_BF16 ? launch256<bf16_t, DFD_EPI_BIAS>(a, st) : launch256<float, DFD_EPI_BIAS>(a, st);

@@ -11,11 +11,16 @@ Kernel sequence per block, rows = clips (B), everything f32 except the K/V strea
   -> dfd_linear_rows(out_proj, +residual) -> LayerNorm -> dfd_linear_rows(c_fc, QuickGELU)
   -> dfd_linear_rows(c_proj, +residual); then dfd_head_fwd (ln_post, projection, 5·z/‖z‖).
 """
+import weakref
+
 import torch
 from torch import nn
 
 from . import capi
 from .encoder import _Holder, _Mlp
+
+# decoder -> {signature: captured graphs}; kept outside the module so that deepcopy / state_dict never see them
+_GRAPHS = weakref.WeakKeyDictionary()
 
 
 class _DecAttnParams(_Holder):
@@ -83,6 +88,11 @@ class Decoder(nn.Module):
             self.task_projections.append([getattr(self, name) for name in names])
         self._wt_cache = {}  # name -> (parameter version, transposed f32 copy) for the row-streaming linear kernel
         self._param_list = None
+        # Opt-in (Detector.static_graphs): the ~450 small launches of one training step of the decoder are
+        # captured into two HIP graphs (forward kernels, backward kernels) per input signature and replayed,
+        # so the host enqueues a step in a few milliseconds however loaded its cores are.  Needs K/V at
+        # stable addresses (Detector keeps persistent export buffers in this mode).
+        self.use_graphs = False
         # decoder blocks start from the encoder layer they read (models.py:226-229)
         for b, l in enumerate(self.layer_indices):
             src, dst = enc.transformer.resblocks[l], self.transformer.resblocks[b]
@@ -400,6 +410,60 @@ class Decoder(nn.Module):
         return grads
 
 
+    # ---- HIP-graph replay of the training-step kernel sequences --------------------------------
+    def _graph_key(self, k_all, v_all, mask, dims, params):
+        return (k_all.data_ptr(), v_all.data_ptr(), str(k_all.dtype), tuple(k_all.shape), dims, tuple(mask.shape),
+                tuple(p.data_ptr() for p in params), self.attn_modes, self.global_prediction)
+
+    def _graph_forward(self, w, k_all, v_all, mask, dims, params):
+        B, T, P = dims
+        key = self._graph_key(k_all, v_all, mask, dims, params)
+        graphs = _GRAPHS.setdefault(self, {})
+        ent = graphs.get(key)
+        if ent is None:
+            if len(graphs) >= 4:  # addresses keep changing: graphs cannot help, stay eager
+                return None
+            ent = dict(mask=mask.clone(), bwd={})
+            self._forward_kernels(w, k_all, v_all, ent["mask"], B, T, P, save=True)  # eager once: lazy initialisations
+            self._wt_cache.clear()  # the weight transposes must be nodes of the graph (weights change every step)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                raws, feat, outs, saved = self._forward_kernels(w, k_all, v_all, ent["mask"], B, T, P, save=True)
+            ent.update(fwd=g, raws=raws, feat=feat, outs=outs, saved=saved)
+            graphs[key] = ent
+        ent["mask"].copy_(mask)
+        ent["fwd"].replay()
+        return ent
+
+    def _graph_backward(self, ent, w, k_all, v_all, dims, d_feat, d_raws, d_logits, want_dkv):
+        B, T, P = dims
+        sig = (d_feat is not None, tuple(t is not None for t in d_raws), tuple(t is not None for t in d_logits), want_dkv)
+        b = ent["bwd"].get(sig)
+        if b is None:
+            b = dict(d_feat=None if d_feat is None else d_feat.contiguous().clone(),
+                     d_raws=[None if t is None else t.contiguous().clone() for t in d_raws],
+                     d_logits=[None if t is None else t.contiguous().clone() for t in d_logits])
+            self._backward_kernels(w, ent["saved"], k_all, v_all, ent["mask"], B, T, P, b["d_feat"], b["d_raws"], b["d_logits"],
+                                   want_dkv)  # eager once
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                grads = self._backward_kernels(w, ent["saved"], k_all, v_all, ent["mask"], B, T, P, b["d_feat"], b["d_raws"],
+                                               b["d_logits"], want_dkv)
+            b.update(graph=g, grads=grads)
+            ent["bwd"][sig] = b
+        if d_feat is not None:
+            b["d_feat"].copy_(d_feat)
+        for dst, src in zip(b["d_raws"] + b["d_logits"], list(d_raws) + list(d_logits)):
+            if src is not None:
+                dst.copy_(src)
+        b["graph"].replay()
+        # parameter gradients leave as copies (autograd may keep or accumulate into what it is handed);
+        # the K/V gradients (adapter training, 1.7 GB each) are consumed immediately and stay in place
+        return {k: (v if k.startswith("__") else v.clone()) for k, v in b["grads"].items()}
+
+
 class _DecoderFn(torch.autograd.Function):
     """autograd node around the decoder's HIP forward / backward kernels.
     Outputs: (video_feature, *raw_logits, *normalised_logits)."""
@@ -408,7 +472,13 @@ class _DecoderFn(torch.autograd.Function):
     def forward(ctx, dec, k_all, v_all, mask, dims, names, *params):
         B, T, P = dims
         w = {n: p.detach() for n, p in zip(names, params)}
-        raws, feat, outs, saved = dec._forward_kernels(w, k_all, v_all, mask, B, T, P, save=True)
+        ent = dec._graph_forward(w, k_all, v_all, mask, dims, params) if dec.use_graphs else None
+        if ent is not None:  # replayed graph: outputs live in the graph's static buffers, hand out copies
+            raws, outs = [t.clone() for t in ent["raws"]], [t.clone() for t in ent["outs"]]
+            feat, saved = ent["feat"].clone(), ent["saved"]
+        else:
+            raws, feat, outs, saved = dec._forward_kernels(w, k_all, v_all, mask, B, T, P, save=True)
+        ctx.graph_entry = ent
         ctx.dec, ctx.w, ctx.saved, ctx.dims, ctx.names = dec, w, saved, dims, names
         ctx.kv = (k_all, v_all, mask)
         ctx.n_out = len(raws)
@@ -422,6 +492,9 @@ class _DecoderFn(torch.autograd.Function):
         k_all, v_all, mask = ctx.kv
         B, T, P = ctx.dims
         want_dkv = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        grads = ctx.dec._backward_kernels(ctx.w, ctx.saved, k_all, v_all, mask, B, T, P, d_feat, d_raws, d_logits, want_dkv)
+        if ctx.graph_entry is not None:
+            grads = ctx.dec._graph_backward(ctx.graph_entry, ctx.w, k_all, v_all, ctx.dims, d_feat, d_raws, d_logits, want_dkv)
+        else:
+            grads = ctx.dec._backward_kernels(ctx.w, ctx.saved, k_all, v_all, mask, B, T, P, d_feat, d_raws, d_logits, want_dkv)
         out = [grads.get(nm) if rq else None for nm, rq in zip(ctx.names, ctx.req)]
         return (None, grads.get("__dk"), grads.get("__dv"), None, None, None, *out)

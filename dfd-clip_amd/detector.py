@@ -185,6 +185,9 @@ class Detector(nn.Module):
         else:
             raise NotImplementedError()
         self.transform = ClipTransform(self.encoder.input_resolution)
+        # opt-in: replay the decoder's training-step kernels as HIP graphs (fixed batch shape; see decoder.py)
+        self.static_graphs = False
+        self._kv_static = None
         # trainable extras (reference models.py:488-496)
         if "temporal" in self.train_mode and self.train_mode.temporal == "ranking":
             self.ranking_transform_param = nn.Parameter((self.encoder.width ** -0.5) * torch.randn(self.encoder.width, 1),
@@ -212,9 +215,22 @@ class Detector(nn.Module):
         # the encoder is frozen and runs without autograd (reference models.py:440, :501); the decoder is
         # differentiable w.r.t. its own parameters
         pos = self.decoder.temporal_pos()
+        self.decoder.use_graphs = False
         masked = train and "patch_mask" in self.train_mode
         if self.adapter is None and not masked:
-            kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos)
+            out = None
+            if self.static_graphs and train:
+                # persistent export buffers: the decoder's HIP graphs need K/V at stable addresses.  What a
+                # previous step returned is overwritten by the next one (only in this opt-in mode).
+                key = (b, t, x.shape[-2:], x.dtype)
+                if self._kv_static is None or self._kv_static[0] != key:
+                    P_ = (self.encoder.input_resolution // self.encoder.patch_size) ** 2
+                    shape = (len(self.layer_indices), b * t * P_, self.encoder.width)
+                    self._kv_static = (key, (torch.empty(shape, device=x.device, dtype=self.encoder.act_dtype),
+                                             torch.empty(shape, device=x.device, dtype=self.encoder.act_dtype)))
+                out = self._kv_static[1]
+            self.decoder.use_graphs = bool(self.static_graphs and train)
+            kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos, out=out)
         elif masked:
             # keep a random subset of patch positions per layer (models.py:511-544): "batch" draws once for all
             # layers, "sample" per layer.  The raw export is row-gathered, then adapter / positional add follow.
