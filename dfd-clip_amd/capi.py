@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT, EPI_RESIDUAL_POS = range(6)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -35,8 +35,8 @@ SIGNATURES = {
     "dfd_abi_version": (c_int, []),
     "dfd_device_check": (c_int, []),
     "dfd_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_float, c_void_p]),
-    "dfd_add_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64,
-                                  c_int, c_float, c_void_p]),
+    "dfd_add_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
+                                  c_int, c_int64, c_int, c_float, c_void_p]),
     "dfd_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dfd_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float),
                                   c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -135,14 +135,15 @@ def layernorm(x, gamma, beta, out, eps=1e-5):
     return out
 
 
-def add_layernorm(x, delta, gamma, beta, out, eps=1e-5):
-    """x[rows, cols] (f32) += delta (f32 / bf16) in place; out = LayerNorm(x) in f32 or bf16."""
-    _dev(x, delta, gamma, beta, out)
+def add_layernorm(x, delta, gamma, beta, out, eps=1e-5, delta2=None, store_x=True):
+    """v = (x + delta) [+ delta2] (x f32, deltas f32 / bf16); out = LayerNorm(v) in f32 or bf16; x <- v when `store_x`."""
+    _dev(x, delta, gamma, beta, out, delta2)
     assert x.dtype == torch.float32 and x.dim() == 2 and out.shape == x.shape and delta.shape == x.shape
     assert x.stride(1) == 1 and out.stride(1) == 1 and delta.stride(1) == 1
-    _check(load_library().dfd_add_layernorm(_ptr(x), x.stride(0), _ptr(delta), delta.stride(0), _DTYPE[delta.dtype], _ptr(gamma),
-                                            _ptr(beta), _ptr(out), out.stride(0), _DTYPE[out.dtype], x.shape[0], x.shape[1], eps,
-                                            _stream()), "dfd_add_layernorm")
+    assert delta2 is None or (delta2.dtype == delta.dtype and delta2.shape == x.shape and delta2.stride() == delta.stride())
+    _check(load_library().dfd_add_layernorm(_ptr(x), x.stride(0), _ptr(delta), _ptr(delta2), delta.stride(0), _DTYPE[delta.dtype],
+                                            int(bool(store_x)), _ptr(gamma), _ptr(beta), _ptr(out), out.stride(0), _DTYPE[out.dtype],
+                                            x.shape[0], x.shape[1], eps, _stream()), "dfd_add_layernorm")
     return out
 
 

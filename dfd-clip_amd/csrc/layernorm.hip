@@ -111,6 +111,7 @@ extern "C" int dfd_layernorm(const float* x, int64_t ldx, const float* gamma, co
 template <typename DeltaT, typename OutT, int SLABS>
 __global__ __launch_bounds__(256) void add_layernorm_rows_kernel(float* __restrict__ x, int64_t ldx,
                                                                  const DeltaT* __restrict__ delta, int64_t ldd,
+                                                                 const DeltaT* __restrict__ delta2, int store_x,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, OutT* __restrict__ y,
                                                                  int64_t ldy, int64_t rows, int cols, float eps) {
@@ -126,16 +127,20 @@ __global__ __launch_bounds__(256) void add_layernorm_rows_kernel(float* __restri
     const int c = (i * 64 + lane) * 4;
     if (c < cols) {
       v[i] = *reinterpret_cast<const f32x4*>(xr + c);
-      if constexpr (sizeof(DeltaT) == 4) {
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dr + c);
+      auto add = [&](const DeltaT* p) {
+        if constexpr (sizeof(DeltaT) == 4) {
+          const f32x4 d = *reinterpret_cast<const f32x4*>(p + c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[i][j] += d[j];
-      } else {
-        const bf16x4 d = *reinterpret_cast<const bf16x4*>(dr + c);
+          for (int j = 0; j < 4; ++j) v[i][j] += d[j];
+        } else {
+          const bf16x4 d = *reinterpret_cast<const bf16x4*>(p + c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[i][j] += (float)d[j];
-      }
-      *reinterpret_cast<f32x4*>(xr + c) = v[i];
+          for (int j = 0; j < 4; ++j) v[i][j] += (float)d[j];
+        }
+      };
+      add(dr);                                             // (x + delta) + delta2: the order of the two
+      if (delta2 != nullptr) add(delta2 + row * ldd);      // separate adds it replaces
+      if (store_x) *reinterpret_cast<f32x4*>(xr + c) = v[i];
       s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     } else {
       v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -178,16 +183,17 @@ __global__ __launch_bounds__(256) void add_layernorm_rows_kernel(float* __restri
 }
 
 template <typename DeltaT, typename OutT>
-static int launch_add_ln(float* x, int64_t ldx, const void* delta, int64_t ldd, const float* g, const float* b, void* y,
-                         int64_t ldy, int64_t rows, int cols, float eps, hipStream_t st) {
+static int launch_add_ln(float* x, int64_t ldx, const void* delta, int64_t ldd, const void* delta2, int store_x, const float* g,
+                         const float* b, void* y, int64_t ldy, int64_t rows, int cols, float eps, hipStream_t st) {
   const int slabs = (cols + 255) / 256;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   const DeltaT* dd = static_cast<const DeltaT*>(delta);
+  const DeltaT* dd2 = static_cast<const DeltaT*>(delta2);
   OutT* yo = static_cast<OutT*>(y);
 #define ALN_CASE(S)                                                                                                   \
   case S:                                                                                                             \
-    hipLaunchKernelGGL((add_layernorm_rows_kernel<DeltaT, OutT, S>), grid, block, 0, st, x, ldx, dd, ldd, g, b, yo, ldy, rows, \
-                       cols, eps);                                                                                    \
+    hipLaunchKernelGGL((add_layernorm_rows_kernel<DeltaT, OutT, S>), grid, block, 0, st, x, ldx, dd, ldd, dd2, store_x, g, b,  \
+                       yo, ldy, rows, cols, eps);                                                                     \
     break;
   switch (slabs) {
     ALN_CASE(1) ALN_CASE(2) ALN_CASE(3) ALN_CASE(4) ALN_CASE(5) ALN_CASE(6) ALN_CASE(7) ALN_CASE(8)
@@ -200,9 +206,9 @@ static int launch_add_ln(float* x, int64_t ldx, const void* delta, int64_t ldd, 
   return DFD_OK;
 }
 
-extern "C" int dfd_add_layernorm(float* x, int64_t ldx, const void* delta, int64_t ldd, int delta_dtype, const float* gamma,
-                                 const float* beta, void* y, int64_t ldy, int y_dtype, int64_t rows, int cols, float eps,
-                                 void* stream) {
+extern "C" int dfd_add_layernorm(float* x, int64_t ldx, const void* delta, const void* delta2, int64_t ldd, int delta_dtype,
+                                 int store_x, const float* gamma, const float* beta, void* y, int64_t ldy, int y_dtype,
+                                 int64_t rows, int cols, float eps, void* stream) {
   DFD_REQUIRE(x && delta && gamma && beta && y, "dfd_add_layernorm: null pointer");
   DFD_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "dfd_add_layernorm: cols=%d must be a multiple of 4, <= 2048", cols);
   DFD_REQUIRE(ldx >= cols && ldd >= cols && ldy >= cols && ldx % 4 == 0 && ldd % 4 == 0 && ldy % 4 == 0,
@@ -211,15 +217,16 @@ extern "C" int dfd_add_layernorm(float* x, int64_t ldx, const void* delta, int64
               "dfd_add_layernorm: pointers must be 16-byte aligned (8 for bf16 operands)");
   DFD_REQUIRE((delta_dtype == DFD_F32 || delta_dtype == DFD_BF16) && (y_dtype == DFD_F32 || y_dtype == DFD_BF16),
               "dfd_add_layernorm: delta_dtype=%d y_dtype=%d", delta_dtype, y_dtype);
-  DFD_REQUIRE(static_cast<const void*>(x) != y && delta != y, "dfd_add_layernorm: y must not alias x or delta");
+  DFD_REQUIRE(static_cast<const void*>(x) != y && delta != y && delta2 != y, "dfd_add_layernorm: y must not alias x or a delta");
+  DFD_REQUIRE(!delta2 || ((uintptr_t)delta2 & 7) == 0, "dfd_add_layernorm: delta2 must be 8-byte aligned");
   if (rows == 0) return DFD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (delta_dtype == DFD_F32) {
-    if (y_dtype == DFD_F32) return launch_add_ln<float, float>(x, ldx, delta, ldd, gamma, beta, y, ldy, rows, cols, eps, st);
-    return launch_add_ln<float, bf16_t>(x, ldx, delta, ldd, gamma, beta, y, ldy, rows, cols, eps, st);
+    if (y_dtype == DFD_F32) return launch_add_ln<float, float>(x, ldx, delta, ldd, delta2, store_x, gamma, beta, y, ldy, rows, cols, eps, st);
+    return launch_add_ln<float, bf16_t>(x, ldx, delta, ldd, delta2, store_x, gamma, beta, y, ldy, rows, cols, eps, st);
   }
-  if (y_dtype == DFD_F32) return launch_add_ln<bf16_t, float>(x, ldx, delta, ldd, gamma, beta, y, ldy, rows, cols, eps, st);
-  return launch_add_ln<bf16_t, bf16_t>(x, ldx, delta, ldd, gamma, beta, y, ldy, rows, cols, eps, st);
+  if (y_dtype == DFD_F32) return launch_add_ln<bf16_t, float>(x, ldx, delta, ldd, delta2, store_x, gamma, beta, y, ldy, rows, cols, eps, st);
+  return launch_add_ln<bf16_t, bf16_t>(x, ldx, delta, ldd, delta2, store_x, gamma, beta, y, ldy, rows, cols, eps, st);
 }
 
 // ---- patchify -----------------------------------------------------------------------------

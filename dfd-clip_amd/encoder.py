@@ -176,7 +176,8 @@ class VisionTransformer(nn.Module):
                 x=torch.zeros(Mp, D, device=dev, dtype=torch.float32), h=torch.zeros(Mp, D, device=dev, dtype=act),
                 mix=torch.zeros(Mp, D, device=dev, dtype=act), u=torch.zeros(Mp, 4 * D, device=dev, dtype=act),
                 patches=torch.zeros(Pp, kpad, device=dev, dtype=act),
-                delta=torch.zeros(Mp, D, device=dev, dtype=act) if self.deferred_residual else None, pending=False,
+                delta=torch.zeros(Mp, D, device=dev, dtype=act) if self.deferred_residual else None,
+                delta2=torch.zeros(Mp, D, device=dev, dtype=act) if self.deferred_residual else None, pending=0,
                 qkv=[torch.zeros(Mp, 3 * D, device=dev, dtype=act) for _ in range(keep_layers)])
             if len(self._ws) > 6:
                 self._ws.clear()
@@ -207,36 +208,45 @@ class VisionTransformer(nn.Module):
         capi.gemm(ws["patches"], p["w_patch"], ws["x"], None, capi.EPI_PATCH_EMBED, m=n * P, pos=p["pos"], cls=p["cls"],
                   tokens=self.tokens)
         M = n * self.tokens
-        ws["pending"] = False
+        ws["pending"] = 0
         capi.layernorm(ws["x"][:M], p["ln_pre"][0], p["ln_pre"][1], ws["x"][:M])
 
-    def _ln(self, ws, gb, M):
-        """h = LayerNorm(x).  On the bf16 path a residual branch that has not been added yet
-        (`ws["pending"]`: out_proj / c_proj wrote it to `ws["delta"]`) is folded in first:
-        x += delta happens inside the same pass over the rows (dfd_add_layernorm)."""
+    def _ln(self, ws, gb, M, store=True):
+        """h = LayerNorm(x).  On the bf16 path the residual branches that have not been added yet
+        (`ws["pending"]` of them: out_proj wrote `ws["delta"]`, c_proj `ws["delta2"]`) are folded in first
+        inside the same pass over the rows (dfd_add_layernorm).  ln_2 (`store=False`) normalises
+        x + delta without storing it; the next ln_1 adds both deltas and stores x once per block."""
         x, h = ws["x"], ws["h"]
-        if ws.get("pending"):
-            capi.add_layernorm(x[:M], ws["delta"][:M], gb[0], gb[1], h[:M])
-            ws["pending"] = False
-        else:
+        pend = ws.get("pending", 0)
+        if pend == 0:
             capi.layernorm(x[:M], gb[0], gb[1], h[:M])
+        elif not store:
+            assert pend == 1
+            capi.add_layernorm(x[:M], ws["delta"][:M], gb[0], gb[1], h[:M], store_x=False)
+        else:
+            capi.add_layernorm(x[:M], ws["delta"][:M], gb[0], gb[1], h[:M], delta2=ws["delta2"][:M] if pend == 2 else None)
+            ws["pending"] = 0
 
     def _residual(self, ws, a, w, b, M):
         """x = x + Linear(a) (model.py:222-223).  fp32 path: read-modify-write of x in the GEMM
         epilogue.  bf16 path: the GEMM stores its output as a bf16 delta (plain store epilogue, a
         quarter of the epilogue bytes) and the add is deferred to the LayerNorm that follows."""
         if self.deferred_residual:
-            assert not ws.get("pending")
-            capi.gemm(a, w, ws["delta"], b, capi.EPI_BIAS, m=M)
-            ws["pending"] = True
+            pend = ws.get("pending", 0)
+            assert pend < 2
+            capi.gemm(a, w, ws["delta2" if pend else "delta"], b, capi.EPI_BIAS, m=M)
+            ws["pending"] = pend + 1
         else:
             capi.gemm(a, w, ws["x"], b, capi.EPI_BIAS_RESIDUAL, m=M)
 
     def _flush(self, ws, M):
         """Materialise x when something other than a LayerNorm reads it next."""
-        if ws.get("pending"):
+        pend = ws.get("pending", 0)
+        if pend >= 1:
             ws["x"][:M] += ws["delta"][:M]
-            ws["pending"] = False
+        if pend == 2:
+            ws["x"][:M] += ws["delta2"][:M]
+        ws["pending"] = 0
 
     def _block(self, ws, bp, qkv, M, n, kv_only=False, export=None):
         """One residual attention block (model.py:220-226).  `export` = (k_out, v_out, tpos, T)
@@ -253,7 +263,7 @@ class VisionTransformer(nn.Module):
             return
         capi.attention_fwd(qkv, ws["mix"], n, self.tokens, self.heads)
         self._residual(ws, ws["mix"], bp["w_out"], bp["b_out"], M)
-        self._ln(ws, bp["ln2"], M)
+        self._ln(ws, bp["ln2"], M, store=False)
         capi.gemm(h, bp["w_fc"], ws["u"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M)
         self._residual(ws, ws["u"], bp["w_proj"], bp["b_proj"], M)
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DFD_ABI_VERSION 7
+#define DFD_ABI_VERSION 8
 
 enum { DFD_F32 = 0, DFD_BF16 = 1 };
 
@@ -70,14 +70,15 @@ int dfd_device_check(void);                /* DFD_OK iff device 0.. current is g
 int dfd_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
                   int y_dtype, int64_t rows, int cols, float eps, void* stream);
 
-/* Residual add fused with the LayerNorm that follows it: x[rows, cols] (f32, updated IN PLACE) +=
- * delta[rows, cols] (delta_dtype), then y = LayerNorm(x) as dfd_layernorm.  The bf16 encoder path has
- * out_proj / c_proj write their output (bias included) as a bf16 delta and folds `x = x + attn(...)`,
- * `x = x + mlp(...)` (clip/model.py:222-223) into the next ln_2 / ln_1 — torch autocast's dataflow.
- * y must not alias x or delta.  cols % 4 == 0, cols <= 2048. */
-int dfd_add_layernorm(float* x, int64_t ldx, const void* delta, int64_t ldd, int delta_dtype, const float* gamma,
-                      const float* beta, void* y, int64_t ldy, int y_dtype, int64_t rows, int cols, float eps,
-                      void* stream);
+/* Residual add fused with the LayerNorm that follows it: v = (x[rows, cols] + delta) [+ delta2], deltas in
+ * delta_dtype with one leading dimension ldd; y = LayerNorm(v) as dfd_layernorm; x (f32) is overwritten with v
+ * when store_x != 0.  The bf16 encoder path has out_proj / c_proj write their output (bias included) as bf16
+ * deltas and folds `x = x + attn(...)`, `x = x + mlp(...)` (clip/model.py:222-223) into the next ln_2 / ln_1 —
+ * torch autocast's dataflow.  ln_2 reads x + delta_attn without storing it; the next ln_1 adds both deltas and
+ * stores x once per block.  delta2 may be NULL.  y must not alias x or a delta.  cols % 4 == 0, cols <= 2048. */
+int dfd_add_layernorm(float* x, int64_t ldx, const void* delta, const void* delta2, int64_t ldd, int delta_dtype,
+                      int store_x, const float* gamma, const float* beta, void* y, int64_t ldy, int y_dtype, int64_t rows,
+                      int cols, float eps, void* stream);
 
 /* Frames [n_frames, 3, res, res] (f32) -> patch rows [n_frames*P, kpad] in out_dtype, column
  * k = c*patch*patch + i*patch + j (the flatten order of conv1.weight [D,3,patch,patch]), columns

@@ -74,6 +74,18 @@ def test_add_layernorm(capi, rows, cols, delta_dtype):
     with pytest.raises(capi.DfdError):
         xd = x.clone().cuda()
         capi.add_layernorm(xd, d.cuda(), g.cuda(), b.cuda(), xd)  # y aliasing x is refused
+    # two deltas, and the non-storing form ln_2 uses
+    d2 = rnd(rows, cols, seed=5).to(delta_dtype)
+    x2 = (x + d.float()) + d2.float()
+    xd = x.clone().cuda()
+    out = torch.empty(rows, cols, device="cuda")
+    capi.add_layernorm(xd, d.cuda(), g.cuda(), b.cuda(), out, delta2=d2.cuda())
+    assert torch.equal(xd.cpu(), x2)
+    assert_close(out, F.layer_norm(x2, (cols,), g, b, 1e-5), 2e-5, msg="two deltas")
+    xd = x.clone().cuda()
+    capi.add_layernorm(xd, d.cuda(), g.cuda(), b.cuda(), out, store_x=False)
+    assert torch.equal(xd.cpu(), x), "store_x=False must leave x untouched"
+    assert_close(out, want, 2e-5, msg="no store")
 
 
 @pytest.mark.parametrize("res,patch,width", [(32, 16, 128), (224, 16, 256), (224, 14, 128)])
