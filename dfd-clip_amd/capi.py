@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT, EPI_RESIDUAL_POS = range(6)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -26,7 +26,7 @@ class DfdError(RuntimeError):
 
 class GemmExtra(Structure):
     _fields_ = [("pos", c_void_p), ("cls", c_void_p), ("k_export", c_void_p), ("v_export", c_void_p),
-                ("tokens", c_int32), ("frames_per_clip", c_int32), ("residual", c_void_p)]
+                ("tokens", c_int32), ("frames_per_clip", c_int32), ("residual", c_void_p), ("qkv_first", c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/dfdclip.h one to one
@@ -207,7 +207,7 @@ def profile_gemm_collect():
 
 
 def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_export=None, v_export=None, tokens=0,
-         frames_per_clip=0, residual=None):
+         frames_per_clip=0, residual=None, qkv_first=0):
     """c = epilogue(a[M,K] @ w[N,K]^T).  `m` limits the rows used (buffers may be over-allocated)."""
     _dev(a, w, c, bias, pos, cls, k_export, v_export, residual)
     assert a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1 and c.stride(1) == 1
@@ -216,7 +216,7 @@ def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_ex
     assert a.shape[1] == K
     assert residual is None or (residual.dtype == c.dtype and residual.stride(0) == c.stride(0))
     extra = GemmExtra(_ptr(pos).value, _ptr(cls).value, _ptr(k_export).value, _ptr(v_export).value, tokens, frames_per_clip,
-                      _ptr(residual).value)
+                      _ptr(residual).value, qkv_first)
     timed = _profile["epilogue"] == epilogue
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

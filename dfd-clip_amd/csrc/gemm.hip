@@ -51,13 +51,14 @@ __device__ __forceinline__ void epilogue_elem(const GemmArgs& a, int64_t m, int 
   } else if constexpr (EPI == DFD_EPI_QKV_EXPORT) {
     const float v = acc + (a.bias ? a.bias[n] : 0.f);
     store_c<CT>(a.C, m * a.ldc + n, v);
-    const int D = a.N / 3;
-    if (a.k_export != nullptr && n >= D) {
+    const int D = a.N / (3 - a.qkv_first);
+    const int ne = n + a.qkv_first * D;  // column in the full [q | k | v] numbering
+    if (a.k_export != nullptr && ne >= D) {
       const int64_t frame = m / a.tokens;
       const int tok = (int)(m - frame * a.tokens);
       if (tok > 0) {
-        const bool is_v = n >= 2 * D;
-        const int cc = n - (is_v ? 2 * D : D);
+        const bool is_v = ne >= 2 * D;
+        const int cc = ne - (is_v ? 2 * D : D);
         const float e = v + (a.pos ? a.pos[(frame % a.frames_per_clip) * D + cc] : 0.f);
         store_c<CT>(is_v ? a.v_export : a.k_export, (frame * (a.tokens - 1) + tok - 1) * D + cc, e);
       }
@@ -297,7 +298,8 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
     DFD_REQUIRE(ldc >= N, "dfd_gemm: ldc=%lld < N", (long long)ldc);
   }
   if (epilogue == DFD_EPI_QKV_EXPORT) {
-    DFD_REQUIRE(extra && extra->tokens > 1 && N % 3 == 0, "dfd_gemm: QKV_EXPORT needs extra.tokens and N %% 3 == 0");
+    DFD_REQUIRE(extra && extra->tokens > 1 && (extra->qkv_first == 0 || extra->qkv_first == 1) && N % (3 - extra->qkv_first) == 0,
+                "dfd_gemm: QKV_EXPORT needs extra.tokens, qkv_first in {0, 1} and N a multiple of the column blocks present");
     DFD_REQUIRE(M % extra->tokens == 0, "dfd_gemm: QKV_EXPORT M=%lld is not a whole number of frames", (long long)M);
     DFD_REQUIRE(!extra->k_export == !extra->v_export, "dfd_gemm: QKV_EXPORT needs both k_export and v_export or neither");
     DFD_REQUIRE(!extra->pos || extra->frames_per_clip > 0, "dfd_gemm: QKV_EXPORT with pos needs frames_per_clip");
@@ -310,6 +312,7 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
     a.pos = extra->pos; a.cls = extra->cls; a.k_export = extra->k_export; a.v_export = extra->v_export;
     a.residual = epilogue == DFD_EPI_RESIDUAL_POS ? extra->residual : nullptr;
     a.tokens = extra->tokens; a.frames_per_clip = extra->frames_per_clip > 0 ? extra->frames_per_clip : 1;
+    a.qkv_first = epilogue == DFD_EPI_QKV_EXPORT ? extra->qkv_first : 0;
   }
   if (M == 0) return DFD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);

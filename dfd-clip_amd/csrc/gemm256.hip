@@ -239,8 +239,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
       b4[j] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nb + j * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     int D = 0, which = 0;
     if constexpr (EPI == DFD_EPI_QKV_EXPORT) {
-      D = a.N / 3;
-      which = n0 / D;  // 0 = q, 1 = k, 2 = v (tiles never straddle: D % 256 == 0)
+      D = a.N / (3 - a.qkv_first);
+      which = n0 / D + a.qkv_first;  // 0 = q, 1 = k, 2 = v (tiles never straddle: D % 256 == 0)
     }
     const bool exporting = EPI == DFD_EPI_QKV_EXPORT && which > 0 && a.k_export != nullptr;
     const int passes = exporting ? 2 : 1;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
           const int64_t m = m0 + wr * 128 + row;
           // 32-bit unsigned division (M < 2^31 is checked by the launcher): the 64-bit form costs ~4x the instructions
           const uint32_t frame = (uint32_t)(m < a.M ? m : a.M - 1) / (uint32_t)a.tokens;
-          const float* pr = a.pos ? a.pos + (int64_t)(frame % (uint32_t)a.frames_per_clip) * D + (nb - which * D) + fq * 4 : nullptr;
+          const float* pr = a.pos ? a.pos + (int64_t)(frame % (uint32_t)a.frames_per_clip) * D + (nb - (which - a.qkv_first) * D) + fq * 4 : nullptr;
 #pragma unroll
           for (int j = 0; j < 4; ++j) p4[j] = pr ? *reinterpret_cast<const f32x4*>(pr + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
             const uint32_t frame = (uint32_t)m / (uint32_t)a.tokens;
             const int tok = (int)((uint32_t)m - frame * (uint32_t)a.tokens);
             if (tok > 0)
-              *reinterpret_cast<uint4*>(dst + ((int64_t)frame * (a.tokens - 1) + tok - 1) * D + (nb - which * D) + c * 8) = d;
+              *reinterpret_cast<uint4*>(dst + ((int64_t)frame * (a.tokens - 1) + tok - 1) * D + (nb - (which - a.qkv_first) * D) + c * 8) = d;
           }
         }
       }
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
 
   int D = 0, which = 0;
   if constexpr (EPI == DFD_EPI_QKV_EXPORT) {
-    D = a.N / 3;
-    which = n0 / D;  // 0 = q, 1 = k, 2 = v (tiles never straddle: D % 256 == 0)
+    D = a.N / (3 - a.qkv_first);
+    which = n0 / D + a.qkv_first;  // 0 = q, 1 = k, 2 = v (tiles never straddle: D % 256 == 0)
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
         }
         if constexpr (EPI == DFD_EPI_QKV_EXPORT) {
           if (erow >= 0) {
-            const int cc = n - which * D;
+            const int cc = n - (which - a.qkv_first) * D;
             if (prow_pos) v += *reinterpret_cast<const f32x4*>(prow_pos + cc);
             void* dst = which == 2 ? a.v_export : a.k_export;
             if constexpr (sizeof(CT) == 2) {
@@ -488,7 +488,7 @@ int DFD_GEMM256_TRY(const GemmArgs& a, int c_dtype, int epi, hipStream_t st) {
     case DFD_EPI_BIAS_QUICKGELU:
       return c_dtype == DFD_BF16 ? launch256<bf16_t, DFD_EPI_BIAS_QUICKGELU>(a, st) : launch256<float, DFD_EPI_BIAS_QUICKGELU>(a, st);
     case DFD_EPI_QKV_EXPORT:
-      if ((a.N / 3) % TN != 0) return 1;
+      if ((a.N / (3 - a.qkv_first)) % TN != 0) return 1;
       if (a.pos && (reinterpret_cast<uintptr_t>(a.pos) & 15) != 0) return 1;
       return c_dtype == DFD_BF16 ? launch256<bf16_t, DFD_EPI_QKV_EXPORT>(a, st) : launch256<float, DFD_EPI_QKV_EXPORT>(a, st);
     case DFD_EPI_BIAS_RESIDUAL:

@@ -14,6 +14,7 @@ struct GemmArgs {
   const void* residual;  // RESIDUAL_POS: source of the residual (NULL = C itself, in place)
   int64_t lda, ldw, ldc, M;
   int N, K, tokens, frames_per_clip;
+  int qkv_first;  // QKV_EXPORT: first column block present (0 = q, 1 = k)
 };
 
 // tuned bf16 kernel (gemm256.hip): 0 = launched, <0 = error, 1 = shape not eligible

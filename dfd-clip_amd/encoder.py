@@ -254,7 +254,12 @@ class VisionTransformer(nn.Module):
         projection (nothing after it can reach an exported tensor)."""
         h = ws["h"]
         self._ln(ws, bp["ln1"], M)
-        if export is not None:
+        if export is not None and kv_only:
+            # last tapped layer: only its K and V are read, so the query third of the projection is skipped too
+            D = self.width
+            capi.gemm(h, bp["w_qkv"][D:], qkv[:, D:], bp["b_qkv"][D:], capi.EPI_QKV_EXPORT, m=M, pos=export[2],
+                      k_export=export[0], v_export=export[1], tokens=self.tokens, frames_per_clip=export[3], qkv_first=1)
+        elif export is not None:
             capi.gemm(h, bp["w_qkv"], qkv, bp["b_qkv"], capi.EPI_QKV_EXPORT, m=M, pos=export[2], k_export=export[0],
                       v_export=export[1], tokens=self.tokens, frames_per_clip=export[3])
         else:

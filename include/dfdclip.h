@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DFD_ABI_VERSION 8
+#define DFD_ABI_VERSION 9
 
 enum { DFD_F32 = 0, DFD_BF16 = 1 };
 
@@ -57,6 +57,8 @@ typedef struct dfd_gemm_extra {
   int32_t tokens;          /* tokens per frame incl. CLS (197 for ViT-B/16) */
   int32_t frames_per_clip; /* T */
   const void* residual;    /* RESIDUAL_POS: residual source in c_dtype with C's leading dimension; NULL = C (in place) */
+  int32_t qkv_first;       /* QKV_EXPORT: 0 = W / C columns are [q | k | v] (N = 3D); 1 = [k | v] only (N = 2D): the last
+                              tapped layer needs no queries (nothing after its K/V export is read) */
 } dfd_gemm_extra;
 
 const char* dfd_last_error(void);          /* host pointer, valid until the thread's next failing call */

@@ -167,6 +167,13 @@ def test_gemm_large_m(capi, M, N):
         pos_f = tpos[torch.arange(Mq // tokens, device="cuda") % T].view(-1, 1, D)
         assert_close(ke.view(-1, tokens - 1, D), fv[:, 1:, 1] + pos_f, 1e-4, 2 ** -8, "k export")
         assert_close(ve.view(-1, tokens - 1, D), fv[:, 1:, 2] + pos_f, 1e-4, 2 ** -8, "v export")
+        # K and V blocks alone (qkv_first=1, what the last tapped layer runs): identical exports and columns
+        ke2, ve2 = torch.full_like(ke, float("nan")), torch.full_like(ve, float("nan"))
+        cq2 = torch.full((Mq, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        capi.gemm(a[:Mq], w[D:], cq2[:, D:], bias[D:], capi.EPI_QKV_EXPORT, pos=tpos, k_export=ke2, v_export=ve2, tokens=tokens,
+                  frames_per_clip=T, qkv_first=1)
+        assert torch.equal(ke2, ke) and torch.equal(ve2, ve) and torch.equal(cq2[:, D:], cq[:, D:])
+        assert torch.isnan(cq2[:, :D].float()).all(), "the query block must not be written"
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -191,6 +198,12 @@ def test_gemm_qkv_export_layout(capi, dtype):
     c2 = torch.empty_like(c)
     capi.gemm(a.to(dtype).cuda(), w.to(dtype).cuda(), c2, bias.cuda(), capi.EPI_QKV_EXPORT, tokens=tokens)  # no export
     assert torch.equal(c, c2)
+    # K | V blocks only (general kernel at this size)
+    ke2, ve2, c3 = torch.zeros_like(ke), torch.zeros_like(ve), torch.zeros_like(c)
+    wd, bd = w.to(dtype).cuda(), bias.cuda()
+    capi.gemm(a.to(dtype).cuda(), wd[D:], c3[:, D:], bd[D:], capi.EPI_QKV_EXPORT, pos=tpos.cuda(), k_export=ke2, v_export=ve2,
+              tokens=tokens, frames_per_clip=T, qkv_first=1)
+    assert torch.equal(ke2, ke) and torch.equal(ve2, ve) and torch.equal(c3[:, D:], c[:, D:]) and (c3[:, :D] == 0).all()
 
 
 @pytest.mark.parametrize("n,tokens,heads", [(2, 5, 2), (3, 197, 4), (1, 257, 2), (2, 50, 12), (64, 197, 12), (45, 200, 12)])
