@@ -15,15 +15,20 @@ def main():
     ap.add_argument("--frames", type=int, default=480)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--pad", action="store_true", help="round M up to a multiple of 256 (what the encoder passes: padded workspaces)")
     args = ap.parse_args()
     capi.load_library()
     M = args.frames * 197
+    if args.pad:
+        M = (M + 255) // 256 * 256
     D = 768
     dev = "cuda"
     shapes = [("qkv", 3 * D, D, capi.EPI_QKV_EXPORT, torch.bfloat16), ("out_proj", D, D, capi.EPI_BIAS_RESIDUAL, torch.float32),
               ("c_fc", 4 * D, D, capi.EPI_BIAS_QUICKGELU, torch.bfloat16), ("c_proj", D, 4 * D, capi.EPI_BIAS_RESIDUAL, torch.float32),
               ("out_proj/d", D, D, capi.EPI_BIAS, torch.bfloat16), ("c_proj/d", D, 4 * D, capi.EPI_BIAS, torch.bfloat16)]
     Mp = (M + 255) // 256 * 256
+    if args.pad:  # padded M is only valid for the plain epilogues (what the encoder uses with padded rows)
+        shapes = [("qkv/plain", 3 * D, D, capi.EPI_BIAS, torch.bfloat16)] + [s_ for s_ in shapes if s_[3] in (capi.EPI_BIAS, capi.EPI_BIAS_QUICKGELU)]
     for name, N, K, epi, cdt in shapes:
         a = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
