@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--no-graphs", action="store_true",
                     help="launch the decoder's training kernels one by one instead of replaying them as HIP graphs")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run the frozen encoder on the same stream as the decoder (no overlap of step N+1's encoder pass "
+                         "with step N's backward / all-reduce / optimizer)")
     ap.add_argument("--ingest", default="f32", choices=["f32", "u8"],
                     help="f32: frames already transformed (the headline's input); u8: raw uint8 frames through the ingest kernel")
     ap.add_argument("--ingest-size", type=int, nargs=2, default=None, metavar=("H", "W"),
@@ -153,7 +156,14 @@ def main():
     ddist.broadcast_parameters(det)
     # the ~450 small decoder launches of a train step replay as two HIP graphs (forward / backward kernels):
     # the host then enqueues a step in a few ms instead of ~14, which keeps the step GPU-bound on a busy host
-    det.static_graphs = not args.no_graphs
+    # (graphs stay off at world > 1: with two ranks sharing one GPU — the only multi-process rehearsal available to
+    # this repo — graph replay + the pipelined encoder + a collective stalled for seconds per step, while either
+    # of them alone ran normally; untested on a real multi-GPU node, so the safe pair is used there)
+    det.static_graphs = (not args.no_graphs) and world == 1
+    # the frozen encoder runs on its own stream: step N+1's encoder pass overlaps step N's decoder backward,
+    # gradient all-reduce and optimizer step (the inputs are resident before the timed region: inputs_ready)
+    det.pipeline_encoder = not args.no_pipeline
+    det.inputs_ready = True
     opt = det.configure_optimizers(0.01 / 25)
     trainable = [p for p in det.parameters() if p.requires_grad]
 
@@ -246,7 +256,7 @@ def main():
                                     f"BASELINE configs[1]: {args.arch} forward-only Detector.predict (inference.py path)")
                                    + f", {B} clips x {T} frames x 3x{res}x{res} per GPU, decode layers {det.layer_indices}, "
                                      f"random-init weights, inputs resident in HBM",
-                       "mode": args.mode, "adapter": args.adapter, "clips_per_gpu": B, "frames_per_clip": T, "hip_graphs": bool(det.static_graphs), "frame_chunk": det.encoder.frame_chunk,
+                       "mode": args.mode, "adapter": args.adapter, "clips_per_gpu": B, "frames_per_clip": T, "hip_graphs": bool(det.static_graphs), "pipelined_encoder": bool(det.pipeline_encoder), "frame_chunk": det.encoder.frame_chunk,
                        "streams": det.encoder.streams},
             "roofline": {"bound": "mfma", "kernel": "c_fc GEMM + QuickGELU (M=%d, N=%d, K=%d)" % (launch_m, 4 * width, width),
                          "achieved": round(achieved, 2) if achieved else None, "peak": peak, "unit": "TFLOP/s",

@@ -93,6 +93,7 @@ class Decoder(nn.Module):
         # so the host enqueues a step in a few milliseconds however loaded its cores are.  Needs K/V at
         # stable addresses (Detector keeps persistent export buffers in this mode).
         self.use_graphs = False
+        self._after_backward = None  # one-shot callback for the next autograd node (Detector's encoder pipelining)
         # decoder blocks start from the encoder layer they read (models.py:226-229)
         for b, l in enumerate(self.layer_indices):
             src, dst = enc.transformer.resblocks[l], self.transformer.resblocks[b]
@@ -479,6 +480,7 @@ class _DecoderFn(torch.autograd.Function):
         else:
             raws, feat, outs, saved = dec._forward_kernels(w, k_all, v_all, mask, B, T, P, save=True)
         ctx.graph_entry = ent
+        ctx.after_backward, dec._after_backward = dec._after_backward, None
         ctx.dec, ctx.w, ctx.saved, ctx.dims, ctx.names = dec, w, saved, dims, names
         ctx.kv = (k_all, v_all, mask)
         ctx.n_out = len(raws)
@@ -497,4 +499,6 @@ class _DecoderFn(torch.autograd.Function):
         else:
             grads = ctx.dec._backward_kernels(ctx.w, ctx.saved, k_all, v_all, mask, B, T, P, d_feat, d_raws, d_logits, want_dkv)
         out = [grads.get(nm) if rq else None for nm, rq in zip(ctx.names, ctx.req)]
+        if ctx.after_backward is not None:
+            ctx.after_backward()
         return (None, grads.get("__dk"), grads.get("__dv"), None, None, None, *out)

@@ -188,6 +188,14 @@ class Detector(nn.Module):
         # opt-in: replay the decoder's training-step kernels as HIP graphs (fixed batch shape; see decoder.py)
         self.static_graphs = False
         self._kv_static = None
+        # opt-in: run the frozen encoder on its own stream so that step N+1's encoder pass overlaps step N's
+        # decoder backward / all-reduce / optimizer (see `predict`); `inputs_ready` = the caller guarantees that
+        # the clips handed to forward() are already complete in device memory
+        self.pipeline_encoder = False
+        self.inputs_ready = False
+        self._enc_stream = None
+        self._pipe_events = [[], []]
+        self._pipe_step = 0
         # trainable extras (reference models.py:488-496)
         if "temporal" in self.train_mode and self.train_mode.temporal == "ranking":
             self.ranking_transform_param = nn.Parameter((self.encoder.width ** -0.5) * torch.randn(self.encoder.width, 1),
@@ -219,18 +227,56 @@ class Detector(nn.Module):
         masked = train and "patch_mask" in self.train_mode
         if self.adapter is None and not masked:
             out = None
-            if self.static_graphs and train:
+            pipelined = bool(self.pipeline_encoder)  # training and inference alike: the decoder of batch N runs
+            #                                            beside the encoder of batch N+1
+            if (self.static_graphs and train) or pipelined:
                 # persistent export buffers: the decoder's HIP graphs need K/V at stable addresses.  What a
-                # previous step returned is overwritten by the next one (only in this opt-in mode).
-                key = (b, t, x.shape[-2:], x.dtype)
+                # previous step returned is overwritten by a later one (only in these opt-in modes).  The
+                # pipelined mode alternates between two sets.
+                key = (b, t, x.shape[-2:], x.dtype, pipelined)
                 if self._kv_static is None or self._kv_static[0] != key:
                     P_ = (self.encoder.input_resolution // self.encoder.patch_size) ** 2
                     shape = (len(self.layer_indices), b * t * P_, self.encoder.width)
-                    self._kv_static = (key, (torch.empty(shape, device=x.device, dtype=self.encoder.act_dtype),
-                                             torch.empty(shape, device=x.device, dtype=self.encoder.act_dtype)))
-                out = self._kv_static[1]
+                    new_set = lambda: (torch.empty(shape, device=x.device, dtype=self.encoder.act_dtype),
+                                       torch.empty(shape, device=x.device, dtype=self.encoder.act_dtype))
+                    self._kv_static = (key, [new_set(), new_set()] if pipelined else [new_set()])
+                    self._pipe_events = [[], []]
+                    self._pipe_step = 0
+                slot = self._pipe_step % len(self._kv_static[1])
+                out = self._kv_static[1][slot]
             self.decoder.use_graphs = bool(self.static_graphs and train)
+            if pipelined:
+                # The frozen encoder does not depend on the decoder's parameters, so the encoder pass of step
+                # N+1 may run while step N's decoder backward, gradient all-reduce and optimizer step are still
+                # executing: it gets its own HIP stream.  It waits for (a) the last readers of the export set it
+                # is about to overwrite (decoder forward / backward of two steps ago), (b) the caller's stream,
+                # unless the caller vouches that the inputs are ready (`inputs_ready`: static or prefetched
+                # batches) — without that the wait includes step N's tail and nothing overlaps.
+                cur = torch.cuda.current_stream()
+                if self._enc_stream is None:
+                    self._enc_stream = torch.cuda.Stream()
+                E = self._enc_stream
+                for ev in self._pipe_events[slot]:
+                    E.wait_event(ev)
+                if not self.inputs_ready:
+                    E.wait_stream(cur)
+                with torch.cuda.stream(E):
+                    kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos, out=out)
+                x.record_stream(E)
+                cur.wait_stream(E)
+                fwd_done, bwd_done = torch.cuda.Event(), torch.cuda.Event()
+                self._pipe_events[slot] = [fwd_done, bwd_done]
+                self.decoder._after_backward = bwd_done.record  # recorded on the backward's stream when it ends
+                self._pipe_step += 1
+                _, video_features, task_logits = self.decoder.run(kv, m)
+                fwd_done.record(cur)
+                features = {"video": video_features} if with_video_features else {}
+                if with_adapt_features:
+                    raise Exception("cannot return adaptive features without an adapter")
+                return task_logits, features
             kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos, out=out)
+            if self.static_graphs and train:
+                self._pipe_step += 1
         elif masked:
             # keep a random subset of patch positions per layer (models.py:511-544): "batch" draws once for all
             # layers, "sample" per layer.  The raw export is row-gathered, then adapter / positional add follow.

@@ -368,3 +368,37 @@ def test_static_graphs_match_eager_training():
         a = det_g(x, [y], m, single_task=0)[1][0]
         b = det_e.eval()(x, [y], m, single_task=0)[1][0]
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_pipelined_encoder_matches_eager_training(graphs):
+    """`Detector.pipeline_encoder` (frozen encoder on its own stream, two alternating K/V export sets, step N+1's
+    encoder pass overlapping step N's backward / optimizer): six steps with changing batches give the same losses,
+    gradients and parameters as the plain single-stream path, bit for bit."""
+    import copy
+    case = build_case("small")
+    det_e = make_detector(case, "bf16")
+    det_p = copy.deepcopy(det_e)
+    det_p.pipeline_encoder, det_p.inputs_ready, det_p.static_graphs = True, True, graphs
+    x, m, y = case["x"].cuda(), case["m"].cuda(), case["y"].cuda()
+    batches = [(x, m, y), (x.flip(0), m.flip(0), y.flip(0)), (x.roll(1, 1), m, y), (x * 0.5, m, y.flip(0)), (x, m, y), (x.flip(1), m, y)]
+    batches = [tuple(t.contiguous() for t in b) for b in batches]
+    torch.cuda.synchronize()  # inputs_ready: every batch is complete in device memory before the loop
+    opt_e, opt_p = det_e.configure_optimizers(0.01), det_p.configure_optimizers(0.01)
+    for step, (xs, ms, ys) in enumerate(batches):
+        res = []
+        for det, opt in ((det_e, opt_e), (det_p, opt_p)):
+            det.train()
+            opt.zero_grad(set_to_none=True)
+            losses, logits, other = det(xs, [ys], ms, train=True, single_task=0)
+            (losses[0].mean() + sum(other.values())).backward()
+            res.append((losses[0].detach().clone(), {n: p.grad.detach().clone() for n, p in det.named_parameters() if p.grad is not None}))
+            opt.step()
+        assert torch.equal(res[0][0], res[1][0]), f"step {step}: losses differ"
+        for n in res[0][1]:
+            assert torch.equal(res[0][1][n], res[1][1][n]), f"step {step}: gradient of {n} differs"
+    for (n, pe), (_, pp) in zip(det_e.named_parameters(), det_p.named_parameters()):
+        assert torch.equal(pe, pp), n
+    det_p.eval()
+    with torch.no_grad():
+        assert torch.equal(det_p(x, [y], m, single_task=0)[1][0], det_e.eval()(x, [y], m, single_task=0)[1][0])
