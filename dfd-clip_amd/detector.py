@@ -254,7 +254,9 @@ class Detector(nn.Module):
                 # batches) — without that the wait includes step N's tail and nothing overlaps.
                 cur = torch.cuda.current_stream()
                 if self._enc_stream is None:
-                    self._enc_stream = torch.cuda.Stream()
+                    # high priority: the encoder's GEMM workgroups are dispatched first, the decoder's small
+                    # latency-bound kernels take what is left over (tile-round tails)
+                    self._enc_stream = torch.cuda.Stream(priority=-1)
                 E = self._enc_stream
                 for ev in self._pipe_events[slot]:
                     E.wait_event(ev)
