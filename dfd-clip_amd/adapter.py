@@ -67,6 +67,7 @@ class CompInvAdapter(nn.Module):
                     seq[4].weight.data.zero_()
                 setattr(self, f"l{i}_{j}", seq)
         self._prep = None
+        self._after_backward = None  # one-shot callback for the next autograd node (Detector's encoder pipelining)
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -197,6 +198,7 @@ class _AdapterFn(torch.autograd.Function):
         w = {n: p.detach() for n, p in zip(names, params)}
         k_out, v_out, a1_all = adapter._forward_train(w, k_raw, v_raw, num_frames, temporal_pos)
         ctx.adapter, ctx.w, ctx.names = adapter, w, names
+        ctx.after_backward, adapter._after_backward = adapter._after_backward, None
         ctx.saved = (k_raw, v_raw, a1_all)
         ctx.req = [p.requires_grad for p in params]
         return k_out, v_out
@@ -206,4 +208,6 @@ class _AdapterFn(torch.autograd.Function):
         k_raw, v_raw, a1_all = ctx.saved
         grads = ctx.adapter._backward_train(ctx.w, k_raw, v_raw, a1_all, dk.contiguous(), dv.contiguous())
         out = [grads.get(nm) if rq else None for nm, rq in zip(ctx.names, ctx.req)]
+        if ctx.after_backward is not None:
+            ctx.after_backward()
         return (None, None, None, None, None, None, *out)

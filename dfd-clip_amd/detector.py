@@ -214,6 +214,53 @@ class Detector(nn.Module):
                 raise NotImplementedError("patch_mask with the nln adapter: its LayerNorm is sized for all patches "
                                           "(the reference fails on this combination too)")
 
+    def _encode(self, x, t, pos, keep):
+        """Encoder pass over the clips -> ((k, v) export, pipeline context or None).
+
+        `keep` / `pipeline_encoder`: the export lands in persistent buffers (what a previous step returned is
+        overwritten by a later one; only in these opt-in modes).  Pipelined: the frozen encoder does not depend
+        on the trainable parameters, so the encoder pass of batch N+1 may run while batch N's decoder (and
+        adapter) backward, gradient all-reduce and optimizer step are still executing.  It gets its own
+        high-priority HIP stream and alternates between two export sets.  It waits for (a) the last readers of
+        the set it is about to overwrite (forward / backward of two batches ago), (b) the caller's stream,
+        unless the caller vouches that the inputs are ready (`inputs_ready`: static or prefetched batches) —
+        without that the wait includes the previous step's tail and nothing overlaps."""
+        b = x.shape[0]
+        pipelined = bool(self.pipeline_encoder)
+        out = None
+        if keep or pipelined:
+            key = (b, t, tuple(x.shape[-2:]), x.dtype, pipelined, pos is None)
+            if self._kv_static is None or self._kv_static[0] != key:
+                P_ = (self.encoder.input_resolution // self.encoder.patch_size) ** 2
+                shape = (len(self.layer_indices), b * t * P_, self.encoder.width)
+                new_set = lambda: (torch.empty(shape, device=x.device, dtype=self.encoder.act_dtype),
+                                   torch.empty(shape, device=x.device, dtype=self.encoder.act_dtype))
+                self._kv_static = (key, [new_set(), new_set()] if pipelined else [new_set()])
+                self._pipe_events = [[], []]
+                self._pipe_step = 0
+            slot = self._pipe_step % len(self._kv_static[1])
+            self._pipe_step += 1
+            out = self._kv_static[1][slot]
+        if not pipelined:
+            return self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos, out=out), None
+        cur = torch.cuda.current_stream()
+        if self._enc_stream is None:
+            # high priority: the encoder's GEMM workgroups are dispatched first, the decoder's small
+            # latency-bound kernels take what is left over (tile-round tails)
+            self._enc_stream = torch.cuda.Stream(priority=-1)
+        E = self._enc_stream
+        for ev in self._pipe_events[slot]:
+            E.wait_event(ev)
+        if not self.inputs_ready:
+            E.wait_stream(cur)
+        with torch.cuda.stream(E):
+            kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos, out=out)
+        x.record_stream(E)
+        cur.wait_stream(E)
+        events = [torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()]  # forward, decoder bwd, adapter bwd
+        self._pipe_events[slot] = events
+        return kv, (cur, *events)
+
     def predict(self, x, m, with_video_features=False, with_adapt_features=False, train=False):
         """x [B,T,3,R,R], m [B,T] bool -> (task_logits list of [B,out_dim] with L2 norm 5, features)."""
         b, t, c, h, w = x.shape
@@ -224,61 +271,11 @@ class Detector(nn.Module):
         # differentiable w.r.t. its own parameters
         pos = self.decoder.temporal_pos()
         self.decoder.use_graphs = False
+        pipe = None
         masked = train and "patch_mask" in self.train_mode
         if self.adapter is None and not masked:
-            out = None
-            pipelined = bool(self.pipeline_encoder)  # training and inference alike: the decoder of batch N runs
-            #                                            beside the encoder of batch N+1
-            if (self.static_graphs and train) or pipelined:
-                # persistent export buffers: the decoder's HIP graphs need K/V at stable addresses.  What a
-                # previous step returned is overwritten by a later one (only in these opt-in modes).  The
-                # pipelined mode alternates between two sets.
-                key = (b, t, x.shape[-2:], x.dtype, pipelined)
-                if self._kv_static is None or self._kv_static[0] != key:
-                    P_ = (self.encoder.input_resolution // self.encoder.patch_size) ** 2
-                    shape = (len(self.layer_indices), b * t * P_, self.encoder.width)
-                    new_set = lambda: (torch.empty(shape, device=x.device, dtype=self.encoder.act_dtype),
-                                       torch.empty(shape, device=x.device, dtype=self.encoder.act_dtype))
-                    self._kv_static = (key, [new_set(), new_set()] if pipelined else [new_set()])
-                    self._pipe_events = [[], []]
-                    self._pipe_step = 0
-                slot = self._pipe_step % len(self._kv_static[1])
-                out = self._kv_static[1][slot]
             self.decoder.use_graphs = bool(self.static_graphs and train)
-            if pipelined:
-                # The frozen encoder does not depend on the decoder's parameters, so the encoder pass of step
-                # N+1 may run while step N's decoder backward, gradient all-reduce and optimizer step are still
-                # executing: it gets its own HIP stream.  It waits for (a) the last readers of the export set it
-                # is about to overwrite (decoder forward / backward of two steps ago), (b) the caller's stream,
-                # unless the caller vouches that the inputs are ready (`inputs_ready`: static or prefetched
-                # batches) — without that the wait includes step N's tail and nothing overlaps.
-                cur = torch.cuda.current_stream()
-                if self._enc_stream is None:
-                    # high priority: the encoder's GEMM workgroups are dispatched first, the decoder's small
-                    # latency-bound kernels take what is left over (tile-round tails)
-                    self._enc_stream = torch.cuda.Stream(priority=-1)
-                E = self._enc_stream
-                for ev in self._pipe_events[slot]:
-                    E.wait_event(ev)
-                if not self.inputs_ready:
-                    E.wait_stream(cur)
-                with torch.cuda.stream(E):
-                    kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos, out=out)
-                x.record_stream(E)
-                cur.wait_stream(E)
-                fwd_done, bwd_done = torch.cuda.Event(), torch.cuda.Event()
-                self._pipe_events[slot] = [fwd_done, bwd_done]
-                self.decoder._after_backward = bwd_done.record  # recorded on the backward's stream when it ends
-                self._pipe_step += 1
-                _, video_features, task_logits = self.decoder.run(kv, m)
-                fwd_done.record(cur)
-                features = {"video": video_features} if with_video_features else {}
-                if with_adapt_features:
-                    raise Exception("cannot return adaptive features without an adapter")
-                return task_logits, features
-            kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos, out=out)
-            if self.static_graphs and train:
-                self._pipe_step += 1
+            kv, pipe = self._encode(x, t, pos, keep=bool(self.static_graphs and train))
         elif masked:
             # keep a random subset of patch positions per layer (models.py:511-544): "batch" draws once for all
             # layers, "sample" per layer.  The raw export is row-gathered, then adapter / positional add follow.
@@ -307,9 +304,15 @@ class Detector(nn.Module):
         else:
             # raw K/V export, then adapter(kv) + pos (models.py:546-549, :326-329); differentiable w.r.t. the
             # adapter's parameters when they are trainable
-            kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, None)
+            kv, pipe = self._encode(x, t, None, keep=False)
+            if pipe is not None:
+                self.adapter._after_backward = pipe[3].record  # its backward is the last reader of the raw export
             kv = self.adapter.run(kv[0], kv[1], t, pos)
+        if pipe is not None:
+            self.decoder._after_backward = pipe[2].record  # recorded on the backward's stream when it ends
         _, video_features, task_logits = self.decoder.run(kv, m)
+        if pipe is not None:
+            pipe[1].record(pipe[0])
         features = {}
         if with_video_features:
             features["video"] = video_features

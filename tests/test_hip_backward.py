@@ -370,13 +370,13 @@ def test_static_graphs_match_eager_training():
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("graphs", [False, True])
-def test_pipelined_encoder_matches_eager_training(graphs):
+@pytest.mark.parametrize("graphs,name", [(False, "small"), (True, "small"), (False, "tiny_adapter_nln"), (False, "tiny_adapter_gl")])
+def test_pipelined_encoder_matches_eager_training(graphs, name):
     """`Detector.pipeline_encoder` (frozen encoder on its own stream, two alternating K/V export sets, step N+1's
     encoder pass overlapping step N's backward / optimizer): six steps with changing batches give the same losses,
     gradients and parameters as the plain single-stream path, bit for bit."""
     import copy
-    case = build_case("small")
+    case = build_case(name)
     det_e = make_detector(case, "bf16")
     det_p = copy.deepcopy(det_e)
     det_p.pipeline_encoder, det_p.inputs_ready, det_p.static_graphs = True, True, graphs
