@@ -1,3 +1,7 @@
+"""Lab diagnostic: host-side time of each phase of a train step (forward / backward / all-reduce / optimizer)
+with two gloo ranks sharing one GPU; G=0/1 toggles the decoder HIP graphs, P=0/1 the pipelined encoder.
+Used to isolate the multi-second all-reduce stalls of graphs + pipelining under GPU oversubscription
+(Multi-GPU).  Run: torchrun --nproc-per-node 2 tools/lab/dbg_pipe.py"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, torch.distributed as dist
