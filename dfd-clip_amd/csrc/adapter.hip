@@ -153,6 +153,99 @@ __device__ __forceinline__ float gelu_erf_grad(float z) {
   return 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
 }
 
+// x == 256 fast paths of the per-row modes (0: GELU(LN(a)), 2: LN(GELU(a))): one wave per row, each lane owns 4
+// consecutive elements loaded once with one 8- or 16-byte access.
+template <typename T> struct Ld4;
+template <> struct Ld4<float> {
+  static __device__ __forceinline__ void load(const float* p, float* o) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = a[e];
+  }
+  static __device__ __forceinline__ void store(float* p, const float* o) { *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]}; }
+};
+template <> struct Ld4<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float* o) {
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (float)a[e];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float* o) {
+    bf16x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (bf16_t)o[e];
+    *reinterpret_cast<bf16x4*>(p) = r;
+  }
+};
+
+template <typename TA, typename T>
+__global__ __launch_bounds__(256) void adapter_row256_kernel(const TA* __restrict__ a, T* __restrict__ y,
+                                                             const float* __restrict__ w, const float* __restrict__ b,
+                                                             int64_t rows, float eps, int gelu_first) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[4], ww[4], bb[4], o[4];
+  Ld4<TA>::load(a + row * 256 + lane * 4, v);
+  Ld4<float>::load(w + lane * 4, ww);
+  Ld4<float>::load(b + lane * 4, bb);
+  if (gelu_first) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+  }
+  const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / 256.0f) + eps);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float z = (v[e] - mean) * rstd * ww[e] + bb[e];
+    o[e] = gelu_first ? z : gelu_erf(z);
+  }
+  Ld4<T>::store(y + row * 256 + lane * 4, o);
+}
+
+// backward group pass for the same modes and width: da and the row's (mean, rstd)
+template <typename TA, typename T>
+__global__ __launch_bounds__(256) void adapter_bwd_row256_kernel(const TA* __restrict__ a, const T* __restrict__ dy,
+                                                                 T* __restrict__ da, const float* __restrict__ w,
+                                                                 const float* __restrict__ b, float* __restrict__ stats,
+                                                                 int64_t rows, float eps, int gelu_first) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float av[4], v[4], dd[4], ww[4], bb[4], g[4], o[4];
+  Ld4<TA>::load(a + row * 256 + lane * 4, av);
+  Ld4<T>::load(dy + row * 256 + lane * 4, dd);
+  Ld4<float>::load(w + lane * 4, ww);
+  Ld4<float>::load(b + lane * 4, bb);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = gelu_first ? gelu_erf(av[e]) : av[e];
+  const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / 256.0f) + eps);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float nh = (v[e] - mean) * rstd;
+    v[e] = nh;
+    g[e] = dd[e] * (gelu_first ? 1.0f : gelu_erf_grad(nh * ww[e] + bb[e])) * ww[e];
+    s1 += g[e];
+    s2 += g[e] * nh;
+  }
+  const float m1 = wave_sum(s1) * (1.0f / 256.0f), m2 = wave_sum(s2) * (1.0f / 256.0f);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float du = rstd * (g[e] - m1 - v[e] * m2);
+    o[e] = gelu_first ? du * gelu_erf_grad(av[e]) : du;
+  }
+  Ld4<T>::store(da + row * 256 + lane * 4, o);
+  if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
 // ---- backward, pass 1: one workgroup per normalisation group (frame slab for "nln", row for "ln") -------
 // da = rstd * (g - mean(g) - nhat * mean(g * nhat)),  g = dy * gelu'(nhat*w + b) * w;  saves (mean, rstd)
 template <typename TA, typename T>
@@ -365,8 +458,14 @@ extern "C" int dfd_adapter_norm_gelu_bwd(const void* a, int a_dtype, const void*
   const int threads = joint ? 1024 : 64;
   const bool reg_ok = joint && group % 8 == 0 && group <= 1024 * 8 * 7 && dfd_aligned16(a) && dfd_aligned16(dy) &&
                       dfd_aligned16(da) && dfd_aligned16(weight) && dfd_aligned16(bias);
+  const bool row256 = !joint && group == 256 && dfd_aligned16(a) && dfd_aligned16(dy) && dfd_aligned16(da) &&
+                      dfd_aligned16(weight) && dfd_aligned16(bias);
 #define ADP_LAUNCH(TA, T)                                                                                                 \
-  if (reg_ok)                                                                                                             \
+  if (row256)                                                                                                             \
+    hipLaunchKernelGGL((adapter_bwd_row256_kernel<TA, T>), dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, st,             \
+                       static_cast<const TA*>(a), static_cast<const T*>(dy), static_cast<T*>(da), weight, bias, stats,      \
+                       groups, eps, gelu_first);                                                                          \
+  else if (reg_ok)                                                                                                        \
     hipLaunchKernelGGL((adapter_bwd_group_reg_kernel<TA, T, 7>), dim3((unsigned)groups), dim3(1024), 0, st,                  \
                        static_cast<const TA*>(a), static_cast<const T*>(dy), static_cast<T*>(da), weight, bias, stats,      \
                        group, eps);                                                                                       \
@@ -403,6 +502,7 @@ extern "C" int dfd_adapter_norm_gelu(const void* a, int a_dtype, void* y, int dt
   // register-resident slab: 16-byte loads need slab % 8 == 0 and aligned bases; 7 chunks x 1024 threads x 8
   const bool reg_ok = slab_all % 8 == 0 && slab_all <= 1024 * 8 * 7 && dfd_aligned16(a) && dfd_aligned16(y) &&
                       dfd_aligned16(weight) && dfd_aligned16(bias);
+  const bool row_ok = dfd_aligned16(a) && dfd_aligned16(y) && dfd_aligned16(weight) && dfd_aligned16(bias);
 #define FWD_LAUNCH(TA, T)                                                                                              \
   do {                                                                                                                 \
     if (joint == 1 && reg_ok)                                                                                          \
@@ -411,6 +511,9 @@ extern "C" int dfd_adapter_norm_gelu(const void* a, int a_dtype, void* y, int dt
     else if (joint == 1)                                                                                               \
       hipLaunchKernelGGL((adapter_nln_kernel<TA, T>), dim3(frames), dim3(1024), 0, st, static_cast<const TA*>(a),        \
                          static_cast<T*>(y), weight, bias, patches * x, eps);                                          \
+    else if (joint != 1 && x == 256 && row_ok)                                                                         \
+      hipLaunchKernelGGL((adapter_row256_kernel<TA, T>), grid, dim3(256), 0, st, static_cast<const TA*>(a),              \
+                         static_cast<T*>(y), weight, bias, rows, eps, gelu_first);                                     \
     else                                                                                                               \
       hipLaunchKernelGGL((adapter_ln_kernel<TA, T>), grid, dim3(256), 0, st, static_cast<const TA*>(a), static_cast<T*>(y), \
                          weight, bias, rows, x, eps, gelu_first);                                                      \

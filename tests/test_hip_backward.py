@@ -275,23 +275,29 @@ def test_gemm_at_b(capi, R, Ma, Nb, dtype):
 @pytest.mark.parametrize("joint", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_adapter_norm_gelu_backward(capi, joint, dtype):
+    """Adapter middle stage, forward and backward, at the shipped width (x = 256: the register-resident joint
+    kernels and the one-wave-per-row kernels) for the three modes: 0 GELU(LN_row), 1 GELU(LN_joint), 2 LN_row(GELU)."""
     frames, P, x = 5, 196, 256
-    a = rnd(frames, P, x, seed=50, scale=1.5).to(dtype).float().requires_grad_(True)
-    shape = (P, x) if joint else (x,)
-    w = (1 + 0.1 * rnd(*shape, seed=51)).requires_grad_(True)
-    b = (0.1 * rnd(*shape, seed=52)).requires_grad_(True)
-    dy = rnd(frames, P, x, seed=53).to(dtype).float()
-    y = F.gelu(F.layer_norm(a, shape, w, b, 1e-5))
-    (y * dy).sum().backward()
-    ad, dyd = a.detach().to(dtype).cuda(), dy.to(dtype).cuda()
-    da = torch.empty_like(ad)
-    dw, db = torch.empty(*shape, device="cuda"), torch.empty(*shape, device="cuda")
-    ws = torch.empty(capi.adapter_norm_gelu_bwd_workspace_bytes(frames, P, x, joint) // 4 + 4, device="cuda")
-    capi.adapter_norm_gelu_bwd(ad, dyd, da, w.detach().cuda(), b.detach().cuda(), dw, db, ws, frames, P, x, joint)
-    tol = 2e-5 if dtype == torch.float32 else 2e-2
-    close(da, a.grad, tol, 1e-3 if dtype == torch.float32 else 2e-2, "da")
-    close(dw, w.grad, 1e-3 if dtype == torch.float32 else 5e-2, 1e-3, "dweight")
-    close(db, b.grad, 1e-3 if dtype == torch.float32 else 5e-2, 1e-3, "dbias")
+    for mode in ((1,) if joint else (0, 2)):
+        a = rnd(frames, P, x, seed=50, scale=1.5).to(dtype).float().requires_grad_(True)
+        shape = (P, x) if joint else (x,)
+        w = (1 + 0.1 * rnd(*shape, seed=51)).requires_grad_(True)
+        b = (0.1 * rnd(*shape, seed=52)).requires_grad_(True)
+        dy = rnd(frames, P, x, seed=53).to(dtype).float()
+        y = F.layer_norm(F.gelu(a), shape, w, b, 1e-5) if mode == 2 else F.gelu(F.layer_norm(a, shape, w, b, 1e-5))
+        (y * dy).sum().backward()
+        ad, dyd = a.detach().to(dtype).cuda(), dy.to(dtype).cuda()
+        yd = torch.empty_like(ad)
+        capi.adapter_norm_gelu(ad, yd, w.detach().cuda(), b.detach().cuda(), frames, P, x, mode)
+        close(yd, y, 2e-5 if dtype == torch.float32 else 2e-2, 1e-3 if dtype == torch.float32 else 2e-2, f"forward mode {mode}")
+        da = torch.empty_like(ad)
+        dw, db = torch.empty(*shape, device="cuda"), torch.empty(*shape, device="cuda")
+        ws = torch.empty(capi.adapter_norm_gelu_bwd_workspace_bytes(frames, P, x, mode) // 4 + 4, device="cuda")
+        capi.adapter_norm_gelu_bwd(ad, dyd, da, w.detach().cuda(), b.detach().cuda(), dw, db, ws, frames, P, x, mode)
+        tol = 2e-5 if dtype == torch.float32 else 2e-2
+        close(da, a.grad, tol, 1e-3 if dtype == torch.float32 else 2e-2, f"da mode {mode}")
+        close(dw, w.grad, 1e-3 if dtype == torch.float32 else 5e-2, 1e-3, f"dweight mode {mode}")
+        close(db, b.grad, 1e-3 if dtype == torch.float32 else 5e-2, 1e-3, f"dbias mode {mode}")
 
 
 @pytest.mark.parametrize("name", ["tiny_ema", "tiny_rank", "tiny_pmask"])
