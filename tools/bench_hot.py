@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""One pass over the encoder's hot kernels at the B16xT30 shapes (for PMC collection under rocprofv3):
+the four GEMMs, both add-LayerNorm forms, plain LayerNorm and the attention kernel, a few launches each."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from dfd_clip_amd import capi  # noqa: E402
+
+capi.load_library()
+frames, tok, H, D = 480, 197, 12, 768
+M = frames * tok
+dev = "cuda"
+bf = torch.bfloat16
+h = torch.randn(M, D, device=dev).to(bf)
+u = torch.randn(M, 4 * D, device=dev).to(bf)
+x = torch.randn(M, D, device=dev)
+d1 = torch.randn(M, D, device=dev).to(bf)
+d2 = torch.randn(M, D, device=dev).to(bf)
+g, b = torch.randn(D, device=dev), torch.randn(D, device=dev)
+wq = (torch.randn(3 * D, D, device=dev) * D ** -0.5).to(bf)
+wo = (torch.randn(D, D, device=dev) * D ** -0.5).to(bf)
+wf = (torch.randn(4 * D, D, device=dev) * D ** -0.5).to(bf)
+wp = (torch.randn(D, 4 * D, device=dev) * (4 * D) ** -0.5).to(bf)
+bq, bo, bf_, bp = (torch.randn(n, device=dev) * 0.1 for n in (3 * D, D, 4 * D, D))
+qkv = torch.empty(M, 3 * D, device=dev, dtype=bf)
+mix = torch.empty(M, D, device=dev, dtype=bf)
+hh = torch.empty(M, D, device=dev, dtype=bf)
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
+    capi.gemm(h, wq, qkv, bq, capi.EPI_QKV_EXPORT, tokens=tok)
+    capi.attention_fwd(qkv, mix, frames, tok, H)
+    capi.gemm(mix, wo, d1, bo, capi.EPI_BIAS)
+    capi.add_layernorm(x, d1, g, b, hh, store_x=False)
+    capi.gemm(hh, wf, u, bf_, capi.EPI_BIAS_QUICKGELU)
+    capi.gemm(u, wp, d2, bp, capi.EPI_BIAS)
+    capi.add_layernorm(x, d1, g, b, hh, delta2=d2)
+    x.mul_(0.5)  # keep the stream bounded over the iterations
+torch.cuda.synchronize()
+print("done")
