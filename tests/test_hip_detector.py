@@ -151,3 +151,26 @@ def test_adapter_stage_full_size(dtype, joint):
         ref = (want[name] + pos).reshape(B * T * P, D)
         err = (got[0].float().cpu() - ref).abs().max().item()
         assert err <= tol, (name, err)
+
+
+@pytest.mark.parametrize("B,T,mask_tail", [(1, 1, 0), (1, 7, 2), (3, 5, 1), (5, 2, 0)])
+def test_ragged_batch_shapes_match_oracle(B, T, mask_tail):
+    """Odd batch / clip sizes (a single clip, a single frame, a ragged last inference chunk) with padded frames:
+    fp32 path against the CPU oracle on the same seeded weights and inputs (the oracle is pinned to the reference
+    by tests/test_oracle_golden.py).  Temporal positional embedding sized for T."""
+    from dfd_clip_amd.detector import Detector
+    from dfd_clip_amd.weights import random_state_dict, synthetic_clips
+    from tests.cases import make_config
+    cfg = make_config("small", decode_mode="index", decode_indices=[0, 2])
+    sd = random_state_dict(cfg, T, seed=11)
+    det = Detector(cfg, T, None, precision="fp32")
+    det.load_state_dict(sd)
+    det = det.cuda().eval()
+    x, m, y = synthetic_clips(B, T, 224, seed=100 + B * 10 + T, masked_tail=False)
+    if mask_tail:
+        m[B - 1, T - mask_tail:] = False
+    with torch.no_grad():
+        logits, feats = det.predict(x.cuda(), m.cuda(), with_video_features=True)
+    want, feat = ref_cpu.detector_predict(sd, x, m, heads=4, patch=16, layer_indices=[0, 2], out_dims=[2], num_frames=T)
+    np.testing.assert_allclose(logits[0].cpu().numpy(), want[0].numpy(), atol=FP32_TOL, rtol=0)
+    np.testing.assert_allclose(feats["video"].cpu().numpy(), feat.numpy(), atol=2 * FP32_TOL, rtol=0)
