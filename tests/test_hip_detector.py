@@ -174,3 +174,36 @@ def test_ragged_batch_shapes_match_oracle(B, T, mask_tail):
     want, feat = ref_cpu.detector_predict(sd, x, m, heads=4, patch=16, layer_indices=[0, 2], out_dims=[2], num_frames=T)
     np.testing.assert_allclose(logits[0].cpu().numpy(), want[0].numpy(), atol=FP32_TOL, rtol=0)
     np.testing.assert_allclose(feats["video"].cpu().numpy(), feat.numpy(), atol=2 * FP32_TOL, rtol=0)
+
+
+def test_full_size_properties_b16_t30():
+    """BASELINE's full size (ViT-B/16, 16 clips x 30 frames, bf16) through size-independent properties of the
+    path: (1) clips are independent — permuting the batch permutes the logits bit for bit; (2) two frame chunks
+    give the same result as one pass; (3) pixels of padded frames cannot influence their clip; (4) logits have
+    L2 norm 5 (reference models.py:551-553)."""
+    from dfd_clip_amd.detector import Detector
+    from dfd_clip_amd.weights import random_state_dict
+    from tests.cases import make_config
+    cfg = make_config("ViT-B/16", decode_mode="index", decode_indices=[6, 7, 8, 9, 10, 11])
+    B, T = 16, 30
+    det = Detector(cfg, T, None, precision="bf16")
+    det.load_state_dict(random_state_dict(cfg, T, seed=0))
+    det = det.cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(B, T, 3, 224, 224, device="cuda", generator=g)
+    m = torch.ones(B, T, dtype=torch.bool, device="cuda")
+    m[3, 20:] = False
+    m[9, 29:] = False
+    with torch.no_grad():
+        base = det.predict(x, m)[0][0].clone()
+        assert torch.isfinite(base).all()
+        np.testing.assert_allclose(base.norm(dim=-1).cpu().numpy(), 5.0, atol=1e-4)
+        perm = torch.randperm(B, device="cuda", generator=g)
+        assert torch.equal(det.predict(x[perm].contiguous(), m[perm].contiguous())[0][0], base[perm]), "clips are not independent"
+        det.encoder.frame_chunk = 8 * T
+        assert torch.equal(det.predict(x, m)[0][0], base), "frame chunking changed the result"
+        det.encoder.frame_chunk = 0
+        x2 = x.clone()
+        x2[3, 20:] = 100.0 * torch.randn_like(x2[3, 20:])
+        x2[9, 29:] = -50.0
+        assert torch.equal(det.predict(x2, m)[0][0], base), "a padded frame influenced its clip"
