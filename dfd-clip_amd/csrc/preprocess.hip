@@ -187,6 +187,46 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(PreArgs a) {
   }
 }
 
+// No-resize fast path for patch rows (patch % 8 == 0, width % 8 == 0): one thread per 8 consecutive output
+// columns = 8 horizontally adjacent pixels of one patch row.  A wave writes 1 KiB of a patch row contiguously
+// (16 B per lane) and reads 8-byte pieces that neighbouring patches complete to full cache lines through L2.
+template <typename OutT>
+__global__ __launch_bounds__(256) void preprocess_identity8_kernel(PreArgs a) {
+  const int p = a.patch;
+  const int P = a.grid_w * a.grid_w;
+  const int per_row = 3 * p * p / 8;  // 8-column groups of real data per patch row
+  const int64_t total = (int64_t)a.n_frames * P * per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int g8 = (int)(idx % per_row);
+    const int64_t prow = idx / per_row;
+    const int pidx = (int)(prow % P);
+    const int64_t n = prow / P;
+    const int k = g8 * 8;
+    const int c = k / (p * p), r = k % (p * p);
+    const int i = r / p, j = r % p;
+    const int y = a.top + (pidx / a.grid_w) * p + i, x = a.left + (pidx % a.grid_w) * p + j;
+    const uint8_t* src = a.src + ((n * 3 + c) * a.in_h + y) * (int64_t)a.in_w + x;
+    uint8_t px[8];
+    if ((reinterpret_cast<uintptr_t>(src) & 7) == 0) {
+      *reinterpret_cast<uint2*>(px) = *reinterpret_cast<const uint2*>(src);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) px[e] = src[e];
+    }
+    const float mean = a.mean[c], stdv = a.stdv[c];
+    OutT* dst = static_cast<OutT*>(a.out) + prow * a.kpad + k;
+    if constexpr (sizeof(OutT) == 2) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(((float)px[e] / 255.f - mean) / stdv);
+      *reinterpret_cast<bf16x8*>(dst) = o;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[e] = ((float)px[e] / 255.f - mean) / stdv;
+    }
+  }
+}
+
 // torchvision.transforms.functional._compute_resized_output_size for an int size
 static void resized_size(int h, int w, int size, int* nh, int* nw) {
   const int s = h < w ? h : w, l = h < w ? w : h;
@@ -249,6 +289,17 @@ extern "C" int dfd_preprocess_u8(const uint8_t* frames, int n_frames, int in_h, 
   const int64_t blocks = (int64_t)n_frames * a.grid_w * a.grid_w * 3;
   DFD_REQUIRE(blocks < (1ll << 31), "dfd_preprocess_u8: too many frames");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a.identity && layout == 1 && patch % 8 == 0 && kpad == 3 * patch * patch && (kpad * (out_dtype == DFD_F32 ? 4 : 2)) % 16 == 0 &&
+      dfd_aligned16(out)) {
+    const int64_t total = (int64_t)n_frames * a.grid_w * a.grid_w * (3 * patch * patch / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 * 16 ? (total + 255) / 256 : 65536 * 16);
+    if (out_dtype == DFD_F32)
+      hipLaunchKernelGGL(preprocess_identity8_kernel<float>, dim3(grid), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(preprocess_identity8_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a);
+    DFD_CHECK_LAUNCH("dfd_preprocess_u8");
+    return DFD_OK;
+  }
   if (out_dtype == DFD_F32) {
     if (lds_bytes > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(&preprocess_u8_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(preprocess_u8_kernel<float>, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
