@@ -15,8 +15,10 @@
 //              to uint8 before ConvertImageDtype); skipped when no resize is needed.
 //   convert  : v / 255, then (v - mean[c]) / std[c]   (IEEE f32 divisions, as ATen does).
 //
-// One 256-thread block per (frame, patch, channel): the source window of the patch is staged in
-// LDS as f32, filtered horizontally into a second LDS buffer, then vertically into registers.
+// One 256-thread block per (frame, patch): the filter taps are computed once and shared by the three
+// channels; per channel the source window of the patch is staged in LDS as f32, filtered horizontally into a
+// second LDS buffer, then vertically into registers.  Without a resize the patch-row form takes a gather
+// kernel instead (8 pixels per thread, 16-byte stores).
 // HBM traffic: u8 source read once (neighbouring blocks share window edges through L2) +
 // output written once; the kernel is bound by that stream.
 #include "common.hpp"
@@ -93,15 +95,12 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(PreArgs a) {
   extern __shared__ float lds[];
   const int p = a.patch;
   const int P = a.grid_w * a.grid_w;
-  const int c = blockIdx.x % 3;
-  const int pidx = (blockIdx.x / 3) % P;
-  const int n = blockIdx.x / (3 * P);
+  const int pidx = blockIdx.x % P;
+  const int n = blockIdx.x / P;
   const int py = pidx / a.grid_w, px = pidx % a.grid_w;
   const int tid = threadIdx.x;
-  const uint8_t* img = a.src + ((int64_t)n * 3 + c) * a.in_h * a.in_w;
-  const float mean = a.mean[c], stdv = a.stdv[c];
 
-  // LDS carve-up: window [win][win] | horizontal result [win][p] | taps
+  // LDS carve-up: window [win][win] | horizontal result [win][p] | taps (shared by the three channels)
   float* win = lds;
   float* hbuf = win + a.win * a.win;
   float* wx = hbuf + a.win * p;               // [p][max_taps]
@@ -112,16 +111,21 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(PreArgs a) {
   int* cy = sy + p;
 
   const int oy0 = a.top + py * p, ox0 = a.left + px * p;
+  auto emit = [&](int c, int i, int j, int e, float o) {
+    if (a.layout == 0) {
+      static_cast<OutT*>(a.out)[(((int64_t)n * 3 + c) * a.res + (py * p + i)) * a.res + px * p + j] = from_f32<OutT>(o);
+    } else {
+      static_cast<OutT*>(a.out)[((int64_t)n * P + pidx) * a.kpad + c * p * p + e] = from_f32<OutT>(o);
+    }
+  };
   if (a.identity) {
     // no resize: plain gather of the patch
-    for (int e = tid; e < p * p; e += 256) {
-      const int i = e / p, j = e % p;
-      const float v = (float)img[(int64_t)(oy0 + i) * a.in_w + ox0 + j];
-      const float o = (v / 255.f - mean) / stdv;
-      if (a.layout == 0) {
-        static_cast<OutT*>(a.out)[(((int64_t)n * 3 + c) * a.res + (py * p + i)) * a.res + px * p + j] = from_f32<OutT>(o);
-      } else {
-        static_cast<OutT*>(a.out)[((int64_t)n * P + pidx) * a.kpad + c * p * p + e] = from_f32<OutT>(o);
+    for (int c = 0; c < 3; ++c) {
+      const uint8_t* img = a.src + ((int64_t)n * 3 + c) * a.in_h * a.in_w;
+      for (int e = tid; e < p * p; e += 256) {
+        const int i = e / p, j = e % p;
+        const float v = (float)img[(int64_t)(oy0 + i) * a.in_w + ox0 + j];
+        emit(c, i, j, e, (v / 255.f - a.mean[c]) / a.stdv[c]);
       }
     }
   } else {
@@ -136,52 +140,52 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(PreArgs a) {
     const int x_lo = sx[0], x_hi = sx[p - 1] + cx[p - 1];
     const int y_lo = sy[0], y_hi = sy[p - 1] + cy[p - 1];
     const int ww = x_hi - x_lo, wh = y_hi - y_lo;  // host sized a.win >= both
-    for (int e = tid; e < wh * ww; e += 256) {
-      const int r = e / ww, q = e % ww;
-      int yy = y_lo + r, xx = x_lo + q;
-      yy = yy < 0 ? 0 : (yy >= a.in_h ? a.in_h - 1 : yy);
-      xx = xx < 0 ? 0 : (xx >= a.in_w ? a.in_w - 1 : xx);
-      win[r * a.win + q] = (float)img[(int64_t)yy * a.in_w + xx];
-    }
-    __syncthreads();
-    // horizontal pass: hbuf[r][j] = sum_k wx[j][k] * win[r][sx[j] - x_lo + k]
-    for (int e = tid; e < wh * p; e += 256) {
-      const int r = e / p, j = e % p;
-      const float* wrow = win + r * a.win + (sx[j] - x_lo);
-      const float* wj = wx + j * a.max_taps;
-      float acc = 0.f;
-      if (!a.antialias) {
-        acc = wrow[0] * wj[0] + wrow[1] * wj[1] + wrow[2] * wj[2] + wrow[3] * wj[3];
-      } else {
-        acc = wrow[0] * wj[0];
-        for (int k = 1; k < cx[j]; ++k) acc += wrow[k] * wj[k];
+    for (int c = 0; c < 3; ++c) {
+      const uint8_t* img = a.src + ((int64_t)n * 3 + c) * a.in_h * a.in_w;
+      const float mean = a.mean[c], stdv = a.stdv[c];
+      if (c > 0) __syncthreads();  // the previous channel's vertical pass is done with hbuf
+      for (int e = tid; e < wh * ww; e += 256) {
+        const int r = e / ww, q = e % ww;
+        int yy = y_lo + r, xx = x_lo + q;
+        yy = yy < 0 ? 0 : (yy >= a.in_h ? a.in_h - 1 : yy);
+        xx = xx < 0 ? 0 : (xx >= a.in_w ? a.in_w - 1 : xx);
+        win[r * a.win + q] = (float)img[(int64_t)yy * a.in_w + xx];
       }
-      hbuf[r * p + j] = acc;
-    }
-    __syncthreads();
-    for (int e = tid; e < p * p; e += 256) {
-      const int i = e / p, j = e % p;
-      const float* wi = wy + i * a.max_taps;
-      const int r0 = sy[i] - y_lo;
-      float acc;
-      if (!a.antialias) {
-        acc = hbuf[r0 * p + j] * wi[0] + hbuf[(r0 + 1) * p + j] * wi[1] + hbuf[(r0 + 2) * p + j] * wi[2] +
-              hbuf[(r0 + 3) * p + j] * wi[3];
-      } else {
-        acc = hbuf[r0 * p + j] * wi[0];
-        for (int k = 1; k < cy[i]; ++k) acc += hbuf[(r0 + k) * p + j] * wi[k];
+      __syncthreads();
+      // horizontal pass: hbuf[r][j] = sum_k wx[j][k] * win[r][sx[j] - x_lo + k]
+      for (int e = tid; e < wh * p; e += 256) {
+        const int r = e / p, j = e % p;
+        const float* wrow = win + r * a.win + (sx[j] - x_lo);
+        const float* wj = wx + j * a.max_taps;
+        float acc = 0.f;
+        if (!a.antialias) {
+          acc = wrow[0] * wj[0] + wrow[1] * wj[1] + wrow[2] * wj[2] + wrow[3] * wj[3];
+        } else {
+          acc = wrow[0] * wj[0];
+          for (int k = 1; k < cx[j]; ++k) acc += wrow[k] * wj[k];
+        }
+        hbuf[r * p + j] = acc;
       }
-      float v = rintf(acc);                        // back onto the uint8 grid (round half even)
-      v = fminf(fmaxf(v, 0.f), 255.f);
-      const float o = (v / 255.f - mean) / stdv;
-      if (a.layout == 0) {
-        static_cast<OutT*>(a.out)[(((int64_t)n * 3 + c) * a.res + (py * p + i)) * a.res + px * p + j] = from_f32<OutT>(o);
-      } else {
-        static_cast<OutT*>(a.out)[((int64_t)n * P + pidx) * a.kpad + c * p * p + e] = from_f32<OutT>(o);
+      __syncthreads();
+      for (int e = tid; e < p * p; e += 256) {
+        const int i = e / p, j = e % p;
+        const float* wi = wy + i * a.max_taps;
+        const int r0 = sy[i] - y_lo;
+        float acc;
+        if (!a.antialias) {
+          acc = hbuf[r0 * p + j] * wi[0] + hbuf[(r0 + 1) * p + j] * wi[1] + hbuf[(r0 + 2) * p + j] * wi[2] +
+                hbuf[(r0 + 3) * p + j] * wi[3];
+        } else {
+          acc = hbuf[r0 * p + j] * wi[0];
+          for (int k = 1; k < cy[i]; ++k) acc += hbuf[(r0 + k) * p + j] * wi[k];
+        }
+        float v = rintf(acc);                        // back onto the uint8 grid (round half even)
+        v = fminf(fmaxf(v, 0.f), 255.f);
+        emit(c, i, j, e, (v / 255.f - mean) / stdv);
       }
     }
   }
-  if (a.layout == 1 && c == 2) {
+  if (a.layout == 1) {
     OutT* row = static_cast<OutT*>(a.out) + ((int64_t)n * P + pidx) * a.kpad;
     for (int k = 3 * p * p + tid; k < a.kpad; k += 256) row[k] = from_f32<OutT>(0.f);
   }
@@ -286,7 +290,7 @@ extern "C" int dfd_preprocess_u8(const uint8_t* frames, int n_frames, int in_h, 
   const size_t lds_bytes = sizeof(float) * ((size_t)a.win * a.win + (size_t)a.win * patch + 2 * (size_t)patch * a.max_taps) +
                            sizeof(int) * 4 * (size_t)patch;
   DFD_REQUIRE(lds_bytes <= 150 * 1024, "dfd_preprocess_u8: downscale %.2fx with patch %d needs %zu B of LDS (> 150 KB)", (double)smax, patch, lds_bytes);
-  const int64_t blocks = (int64_t)n_frames * a.grid_w * a.grid_w * 3;
+  const int64_t blocks = (int64_t)n_frames * a.grid_w * a.grid_w;
   DFD_REQUIRE(blocks < (1ll << 31), "dfd_preprocess_u8: too many frames");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a.identity && layout == 1 && patch % 8 == 0 && kpad == 3 * patch * patch && (kpad * (out_dtype == DFD_F32 ? 4 : 2)) % 16 == 0 &&
