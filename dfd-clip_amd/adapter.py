@@ -26,6 +26,7 @@ import torch
 from torch import nn
 
 from . import capi
+from .encoder import RuntimeStateMixin
 
 # struct -> (index of the LayerNorm and of the output Linear inside the reference's nn.Sequential, kernel mode:
 # 0 = GELU(LN_row(a)), 1 = GELU(LN_joint(a)), 2 = LN_row(GELU(a)))   (reference models.py:795-875)
@@ -34,7 +35,12 @@ _STRUCTS = {"768-x-768-nln": (1, 4, 1), "768-x-768-ln": (1, 4, 0), "768-x-768-z0
 _SUPPORTED = tuple(_STRUCTS)
 
 
-class CompInvAdapter(nn.Module):
+class CompInvAdapter(RuntimeStateMixin, nn.Module):
+    _RUNTIME_STATE = {"_prep": None, "_after_backward": None}
+
+    def invalidate_caches(self):
+        self._prep = None
+
     def __init__(self, config, detector, num_frames=50):
         super().__init__()
         enc = detector.encoder

@@ -33,6 +33,7 @@ class GemmExtra(Structure):
 SIGNATURES = {
     "dfd_last_error": (c_char_p, []),
     "dfd_abi_version": (c_int, []),
+    "dfd_gemm_last_path": (c_int, []),
     "dfd_device_check": (c_int, []),
     "dfd_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_float, c_void_p]),
     "dfd_add_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
@@ -227,6 +228,11 @@ def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_ex
         e1.record()
         _profile["events"].append((e0, e1, 2.0 * M * N * K))
     return c
+
+
+def gemm_last_path():
+    """256 when this thread's last gemm ran on the tuned 256x256 bf16 kernel, 128 for the general kernel."""
+    return load_library().dfd_gemm_last_path()
 
 
 def gemm_at_b_workspace_bytes(R, Ma, Nb, dtype):

@@ -275,6 +275,9 @@ int launch_at_b(const void* A, int64_t lda, const void* B, int64_t ldb, float* C
 
 }  // namespace
 
+static thread_local int g_last_path = 0;
+extern "C" int dfd_gemm_last_path(void) { return g_last_path; }
+
 extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int ab_dtype, void* C, int64_t ldc,
                         int c_dtype, const float* bias, int epilogue, const dfd_gemm_extra* extra, int64_t M, int N,
                         int K, void* stream) {
@@ -318,8 +321,10 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (ab_dtype == DFD_BF16) {
     const int rc = dfd_gemm256_try(a, c_dtype, epilogue, st);
+    if (rc == 0) g_last_path = 256;
     if (rc <= 0) return rc;
   }
+  g_last_path = 128;
   if (ab_dtype == DFD_F32) return launch_gemm128<float, float>(a, epilogue, st);
   if (c_dtype == DFD_BF16) return launch_gemm128<bf16_t, bf16_t>(a, epilogue, st);
   return launch_gemm128<bf16_t, float>(a, epilogue, st);

@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from . import capi
-from .encoder import _Holder, _Mlp
+from .encoder import RuntimeStateMixin, _Holder, _Mlp
 
 # decoder -> {signature: captured graphs}; kept outside the module so that deepcopy / state_dict never see them
 _GRAPHS = weakref.WeakKeyDictionary()
@@ -52,7 +52,14 @@ class DecoderTransformer(_Holder):
         self.resblocks = nn.Sequential(*[DecoderBlock(width) for _ in range(n_blocks)])
 
 
-class Decoder(nn.Module):
+class Decoder(RuntimeStateMixin, nn.Module):
+    _RUNTIME_STATE = {"_wt_cache": {}, "_after_backward": None, "_param_list": None}
+
+    def invalidate_caches(self):
+        """After parameters were rewritten in place behind autograd's back."""
+        self._wt_cache = {}
+        _GRAPHS.pop(self, None)
+
     def __init__(self, detector, config, num_frames):
         super().__init__()
         enc = detector.encoder

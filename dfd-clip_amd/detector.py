@@ -27,7 +27,7 @@ from . import capi
 from .config import default_detector_config
 from .adapter import CompInvAdapter
 from .decoder import Decoder
-from .encoder import VisionTransformer
+from .encoder import RuntimeStateMixin, VisionTransformer
 from .weights import ARCHS, resolve_layer_indices
 
 CLIP_CACHE = os.path.expanduser("~/.cache/clip")  # where the reference's downloader leaves checkpoints (clip/clip.py:94)
@@ -74,18 +74,52 @@ def _infer_arch_from_state_dict(sd):
     return grid * patch, patch, width, layers, width // 64, sd["proj"].shape[1]
 
 
+def _is_torchscript_archive(path):
+    """The published CLIP checkpoints (ViT-B-16.pt, ...) are TorchScript archives: a zip whose root folder holds
+    `constants.pkl` next to `data.pkl` (and `code/`).  A plain `torch.save` state_dict has `data.pkl` only."""
+    import zipfile
+    if not zipfile.is_zipfile(path):
+        return False
+    with zipfile.ZipFile(path) as z:
+        names = z.namelist()
+    return any(n.endswith("/constants.pkl") or "/code/" in n for n in names)
+
+
+def _halved_by_convert_weights(key):
+    """Parameters the reference's `convert_weights` stores in fp16 before `load_state_dict` copies the checkpoint
+    in (reference `src/clip/model.py:429-450`): Conv/Linear weights and biases and `proj`.  Its custom attention
+    class is not `nn.MultiheadAttention`, so `in_proj_weight` / `in_proj_bias` stay fp32, as do LayerNorms and
+    the class / positional embeddings."""
+    return key == "conv1.weight" or key == "proj" or ".out_proj." in key or ".mlp.c_fc." in key or ".mlp.c_proj." in key
+
+
 def load_clip_visual(name, precision):
     """Counterpart of `clip.load(name)[0].visual.float()` (reference `src/models.py:440`,
-    `src/clip/clip.py:94-142`).  The reference downloads the checkpoint by name; there is no
-    network here, so: a path to a state_dict checkpoint (or `~/.cache/clip/<name>.pt`) is loaded
-    with `weights_only=True`; otherwise the architecture is built with its seeded random
-    initialisation and a warning is logged."""
+    `src/clip/clip.py:94-142`, `src/clip/model.py:453-496`).  The reference downloads the checkpoint by name;
+    there is no network here, so: a path to a state_dict checkpoint (or `~/.cache/clip/<name>.pt`, where the
+    reference's downloader leaves it) is loaded with `weights_only=True`; otherwise the architecture is built
+    with its seeded random initialisation and a warning is logged.
+
+    The architecture is read off the tensor shapes as `build_model` does, and the weights take the same path
+    through fp16 as in the reference: `convert_weights` halves the Conv/Linear parameters and `proj` before the
+    checkpoint is copied in, `.float()` widens them again, so an fp32 checkpoint loses those mantissa bits here
+    too (an fp16 checkpoint, the published form, is unchanged by it)."""
     path = name if os.path.isfile(name) else os.path.join(CLIP_CACHE, name.replace("/", "-") + ".pt")
     if os.path.isfile(path):
+        if _is_torchscript_archive(path):
+            raise RuntimeError(
+                f"{path} is a TorchScript archive (the form OpenAI publishes); this loader reads plain state_dict "
+                "checkpoints only (torch.load(weights_only=True) executes nothing from the file).  Convert it once, "
+                "offline, where you trust the file:  torch.save(torch.jit.load(path, map_location='cpu').state_dict(), "
+                "new_path)  and point `architecture` at new_path.")
         sd = torch.load(path, map_location="cpu", weights_only=True)
+        if not isinstance(sd, dict) or not all(isinstance(v, torch.Tensor) for v in sd.values()):
+            raise RuntimeError(f"{path}: expected a state_dict (name -> tensor), got {type(sd).__name__}")
         sd = {k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")} or sd
+        if "conv1.weight" not in sd or "proj" not in sd:
+            raise RuntimeError(f"{path}: no CLIP ViT visual tower in this checkpoint (ResNet towers are not built)")
         vit = VisionTransformer(*_infer_arch_from_state_dict(sd), precision=precision)
-        vit.load_state_dict({k: v.float() for k, v in sd.items()})
+        vit.load_state_dict({k: (v.half().float() if _halved_by_convert_weights(k) else v.float()) for k, v in sd.items()})
         return vit
     if name not in ARCHS:
         raise RuntimeError(f"Model {name} not found; available architectures = {list(ARCHS)}")
@@ -138,7 +172,18 @@ class ClipTransform:
         return (x - mean) / std
 
 
-class Detector(nn.Module):
+class Detector(RuntimeStateMixin, nn.Module):
+    _RUNTIME_STATE = {"_kv_static": None, "_enc_stream": None, "_pipe_events": [[], []], "_pipe_step": 0, "_pos_snap": None}
+
+    def invalidate_caches(self):
+        """Drop every device-side copy derived from the parameters (bf16 encoder weights, transposed decoder
+        weights, adapter operands, captured graphs).  `load_state_dict` / `.to()` / optimizer steps are tracked
+        automatically; call this after writing parameters in place by other means (`dist.broadcast_parameters`)."""
+        self.encoder.invalidate()
+        self.decoder.invalidate_caches()
+        if self.adapter is not None:
+            self.adapter.invalidate_caches()
+
     @staticmethod
     def get_default_config():
         return default_detector_config()
@@ -196,6 +241,7 @@ class Detector(nn.Module):
         self._enc_stream = None
         self._pipe_events = [[], []]
         self._pipe_step = 0
+        self._pos_snap = None
         # trainable extras (reference models.py:488-496)
         if "temporal" in self.train_mode and self.train_mode.temporal == "ranking":
             self.ranking_transform_param = nn.Parameter((self.encoder.width ** -0.5) * torch.randn(self.encoder.width, 1),
@@ -253,8 +299,23 @@ class Detector(nn.Module):
             E.wait_event(ev)
         if not self.inputs_ready:
             E.wait_stream(cur)
+        pos_ready = None
+        if pos is not None:
+            # `pos` is a view of a TRAINABLE parameter and stream E does not wait for the caller's stream
+            # (inputs_ready): read live, step N+1's export could see a positional embedding that step N's
+            # optimizer is still writing.  So the value is snapshotted on the caller's stream — after everything
+            # already queued there, i.e. after the previous optimizer step, which is the value the reference
+            # reads — and E waits for that copy only where it first needs it, at the first tapped layer's
+            # projection: the layers below it still overlap the previous step's backward and optimizer.
+            if self._pos_snap is None or self._pos_snap[0].shape != pos.shape or self._pos_snap[0].device != pos.device:
+                self._pos_snap = [torch.empty_like(pos), torch.empty_like(pos)]
+            snap = self._pos_snap[slot]
+            snap.copy_(pos)
+            pos_ready = torch.cuda.Event()
+            pos_ready.record(cur)
+            pos = snap
         with torch.cuda.stream(E):
-            kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos, out=out)
+            kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos, out=out, pos_ready=pos_ready)
         x.record_stream(E)
         cur.wait_stream(E)
         events = [torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()]  # forward, decoder bwd, adapter bwd

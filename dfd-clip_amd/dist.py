@@ -18,6 +18,19 @@ import torch.distributed as dist
 from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 
 
+_STAGE_GLOO = True
+_PINNED = {}
+
+
+def _pinned_like(t):
+    key = (t.numel(), t.dtype)
+    buf = _PINNED.get(key)
+    if buf is None:
+        _PINNED.clear()
+        buf = _PINNED[key] = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+    return buf
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -30,17 +43,21 @@ def broadcast_parameters(module, src=0):
     """Make every rank start from rank `src`'s parameters and buffers (DDP does this at wrap time)."""
     if world_size() == 1:
         return
-    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    tensors = list(module.parameters()) + list(module.buffers())
     if not tensors:
         return
     by_dtype = {}
     for t in tensors:
         by_dtype.setdefault(t.dtype, []).append(t)
-    for group in by_dtype.values():
-        flat = _flatten_dense_tensors(group)
-        dist.broadcast(flat, src)
-        for t, f in zip(group, _unflatten_dense_tensors(flat, group)):
-            t.copy_(f)
+    with torch.no_grad():
+        for group in by_dtype.values():
+            flat = _flatten_dense_tensors([t.detach() for t in group])
+            dist.broadcast(flat, src)
+            for t, f in zip(group, _unflatten_dense_tensors(flat, group)):
+                t.copy_(f)  # on the parameter itself: bumps its version counter, which the weight caches key on
+    for sub in module.modules():  # device-side copies derived from the parameters (bf16 / transposed weights, graphs)
+        if hasattr(sub, "invalidate_caches"):
+            sub.invalidate_caches()
 
 
 def allreduce_gradients(params):
@@ -55,7 +72,19 @@ def allreduce_gradients(params):
             p.grad = torch.zeros_like(p)
     grads = [p.grad for p in params]
     flat = _flatten_dense_tensors(grads)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if flat.is_cuda and dist.get_backend() == "gloo" and _STAGE_GLOO:
+        # gloo has no device path: ProcessGroupGloo stages a CUDA tensor through a pinned host buffer it allocates
+        # per call.  Entered while the device still has work queued, that allocation cannot reuse the previous
+        # step's block (its copy event is still pending), so every step pins and unpins another 156 MB — the
+        # multi-second "stall" of round 1's one-GPU rehearsal (tools/lab/dbg_pipe.py).  Stage through ONE
+        # persistent pinned buffer instead; RCCL ("nccl") reduces device buffers directly and never comes here.
+        host = _pinned_like(flat)
+        host.copy_(flat, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host, non_blocking=True)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat.div_(n)
     for g, f in zip(grads, _unflatten_dense_tensors(flat, grads)):
         g.copy_(f)

@@ -24,12 +24,29 @@ epilogue: `[N*P, D]` per selected layer, CLS row dropped, temporal positional em
 layer that cannot reach any exported tensor.
 """
 import contextlib
-import os
 
 import torch
 from torch import nn
 
 from . import capi
+
+
+class RuntimeStateMixin:
+    """Per-process runtime state (device caches, streams, events, captured graphs) is not part of the model:
+    `copy.deepcopy` (the trainer's teacher mode, reference `src/trainer.py:68`) gives the copy fresh, empty
+    state instead of duplicating gigabytes of cached buffers or sharing streams and events."""
+    _RUNTIME_STATE = {}
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in self._RUNTIME_STATE:
+                new.__dict__[k] = copy.deepcopy(self._RUNTIME_STATE[k])
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
 
 class _Holder(nn.Module):
@@ -74,7 +91,9 @@ class Transformer(_Holder):
         self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads) for _ in range(layers)])
 
 
-class VisionTransformer(nn.Module):
+class VisionTransformer(RuntimeStateMixin, nn.Module):
+    _RUNTIME_STATE = {"_prepared": None, "_ws": {}, "_side_streams": []}
+
     def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim, precision="bf16"):
         super().__init__()
         assert width % heads == 0 and width // heads == 64, "kernels are built for 64-wide heads"
@@ -109,7 +128,7 @@ class VisionTransformer(nn.Module):
         self.antialias = True
         # bf16 path: residual branches are stored as bf16 deltas and added inside the next LayerNorm
         # (see `_residual`); the fp32 parity path keeps the read-modify-write epilogue
-        self.deferred_residual = precision == "bf16" and os.environ.get("DFD_DEFERRED_RESIDUAL", "1") != "0"
+        self.deferred_residual = precision == "bf16"
 
     # ---- derived device-side operands ---------------------------------------------------
     @property
@@ -299,11 +318,14 @@ class VisionTransformer(nn.Module):
         return result
 
     @torch.no_grad()
-    def extract_kv(self, x, layer_indices, num_frames, temporal_pos=None, out=None):
+    def extract_kv(self, x, layer_indices, num_frames, temporal_pos=None, out=None, pos_ready=None):
         """Fused extraction for the decoder: frames [N,3,R,R] (N = B*T) ->
         (k, v): two tensors [L, N*P, D] in the activation dtype, one slab per selected layer,
         rows ordered (clip, frame, patch) — i.e. `[B, T*P, heads, 64]` per layer — with the
-        temporal positional embedding `temporal_pos` [T, D] (f32) added when given."""
+        temporal positional embedding `temporal_pos` [T, D] (f32) added when given.
+        `pos_ready`: an event that must have fired before `temporal_pos` is read (the pipelined encoder
+        stream, `Detector._encode`): waited for right before the first tapped layer's projection, so the
+        layers below it do not wait."""
         if not x.is_cuda:
             raise capi.DfdError("the encoder runs on HIP kernels only: pass device tensors")
         p = self._prepare()
@@ -341,10 +363,14 @@ class VisionTransformer(nn.Module):
                 qkv = ws["qkv"][0]
                 M = nf * tok
                 self._embed(frames[f0:f0 + nf], ws, p)
+                waited = pos_ready is None or temporal_pos is None
                 for l in range(last + 1):
                     exp = None
                     if l in slot:
                         i = slot[l]
+                        if not waited:
+                            torch.cuda.current_stream().wait_event(pos_ready)
+                            waited = True
                         exp = (k_out[i, f0 * P:(f0 + nf) * P], v_out[i, f0 * P:(f0 + nf) * P], temporal_pos, num_frames)
                     self._block(ws, p["blocks"][l], qkv, M, nf, kv_only=(l == last), export=exp)
         if n_str > 1:

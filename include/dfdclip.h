@@ -110,6 +110,9 @@ int dfd_preprocess_geometry(int in_h, int in_w, int res, int* rs_h, int* rs_w, i
 int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int ab_dtype, void* C, int64_t ldc,
              int c_dtype, const float* bias, int epilogue, const dfd_gemm_extra* extra, int64_t M, int N, int K,
              void* stream);
+/* Which kernel served this thread's last successful dfd_gemm: 256 = the tuned 256x256 bf16 kernel (M >= 1024,
+ * N % 256 == 0, K % 64 == 0, K >= 128), 128 = the general 128x128 kernel, 0 = none yet.  For tests and profilers. */
+int dfd_gemm_last_path(void);
 
 /* C[Ma, Nb] (f32) = Aᵀ · B for tall row-major operands A [R, Ma], B [R, Nb] in `dtype` — the weight
  * gradient of a Linear applied to R rows (adapter training: R = B·T·patches).  Internally: zero-padded

@@ -131,6 +131,8 @@ CASES = {
     "small": ("small", 2, 3, dict(decode_mode="index", decode_indices=[1, 2]), "medium"),
     "small14": ("small14", 2, 3, dict(decode_mode="index", decode_indices=[0, 1]), "medium"),
     "vitb16_cfg1": ("ViT-B/16", 2, 8, dict(decode_mode="index", decode_indices=[6, 7, 8, 9, 10, 11]), "slices"),
+    # BASELINE configs[3]'s architecture (width 1024, 24 layers, 16 heads, 257 tokens, patch K = 588), every other layer tapped
+    "vitl14": ("ViT-L/14", 2, 2, dict(decode_mode="stride", decode_stride=2), "slices"),
     # training-mode extras (reference models.py:511-544, :572-578, :598-736)
     "tiny_ema": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], op_mode__ema_frame=0.3,
                                     op_mode__temporal_position=0), "light"),
@@ -162,6 +164,15 @@ def run_case(name, mm, Acc, to_cn):
     out["logits"] = logits[0].numpy()
     out["losses"] = losses[0].numpy()
     out["video_feature"] = feats["video"].numpy()
+    # the reference's own bf16 mixed-precision run (Accelerate `mixed_precision: bf16` = torch.autocast around the
+    # forward): the pin for the bf16 HIP path, which cannot be held to the fp32 outputs' 1e-3
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        losses_a, logits_a = det(x, [y], m, single_task=0)
+        _, feats_a = det.predict(x, m, with_video_features=True)
+        enc_a = det.encoder(x.flatten(0, 1))
+    out["logits_bf16"] = logits_a[0].float().numpy()
+    out["losses_bf16"] = losses_a[0].float().numpy()
+    out["video_feature_bf16"] = feats_a["video"].float().numpy()
     if "ema_frame" not in str(over):  # forward() averages the frames first (models.py:572-578), predict() does not
         assert torch.equal(plog[0], logits[0])
     lidx = det.layer_indices
@@ -176,6 +187,7 @@ def run_case(name, mm, Acc, to_cn):
             for key in ("k", "v"):
                 for fr in (0, B * T - 1):
                     out[f"enc{l}_{key}_f{fr}"] = enc[l][key][fr, rows].numpy()
+                    out[f"enc{l}_{key}_f{fr}_bf16"] = enc_a[l][key][fr, rows].float().numpy()
         out["slice_rows"] = np.asarray(rows)
         out[f"enc{layers - 1}_out_f0"] = enc[layers - 1]["out"][0, rows].numpy()
     elif store == "slices":
@@ -184,6 +196,7 @@ def run_case(name, mm, Acc, to_cn):
             for key in ("k", "v"):
                 for fr in (0, B * T - 1):
                     out[f"enc{l}_{key}_f{fr}"] = enc[l][key][fr, rows].numpy()
+                    out[f"enc{l}_{key}_f{fr}_bf16"] = enc_a[l][key][fr, rows].float().numpy()
         out["slice_rows"] = np.asarray(rows)
         out[f"enc{layers - 2}_out_f0"] = enc[layers - 2]["out"][0, rows].numpy()
     # training contract: forward(train=True) -> backward(mean loss) -> two SGD steps on one batch

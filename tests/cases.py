@@ -29,6 +29,7 @@ CASES = {
     "small": ("small", 2, 3, dict(decode_mode="index", decode_indices=[1, 2])),
     "small14": ("small14", 2, 3, dict(decode_mode="index", decode_indices=[0, 1])),
     "vitb16_cfg1": ("ViT-B/16", 2, 8, dict(decode_mode="index", decode_indices=[6, 7, 8, 9, 10, 11])),
+    "vitl14": ("ViT-L/14", 2, 2, dict(decode_mode="stride", decode_stride=2)),
     "tiny_ema": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], op_mode__ema_frame=0.3,
                                     op_mode__temporal_position=0)),
     "tiny_rank": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], train_mode__temporal="ranking")),

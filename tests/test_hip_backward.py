@@ -408,3 +408,54 @@ def test_pipelined_encoder_matches_eager_training(graphs, name):
     det_p.eval()
     with torch.no_grad():
         assert torch.equal(det_p(x, [y], m, single_task=0)[1][0], det_e.eval()(x, [y], m, single_task=0)[1][0])
+
+
+def test_pipelined_encoder_full_size_trainable_positional_embedding():
+    """the pipelined encoder stream must not read the TRAINABLE temporal positional embedding
+    while the previous step's optimizer is writing it.  Full size (ViT-B/16, 16 clips x 30 frames, bf16), large
+    learning rate on the positional embedding, six back-to-back steps with NO host synchronisation (the host runs
+    several steps ahead of the device, as in bench.py), graphs + pipelining + inputs_ready — against the plain
+    single-stream path run afterwards: losses and every parameter bit-identical."""
+    import copy
+    from dfd_clip_amd.detector import Detector
+    from dfd_clip_amd.weights import random_state_dict
+    from tests.cases import make_config
+    cfg = make_config("ViT-B/16", decode_mode="index", decode_indices=[6, 7, 8, 9, 10, 11])
+    B, T = 16, 30
+    det_e = Detector(cfg, T, None, precision="bf16")
+    det_e.load_state_dict(random_state_dict(cfg, T, seed=0))
+    det_e = det_e.cuda().train()
+    det_p = copy.deepcopy(det_e)
+    det_p.pipeline_encoder, det_p.inputs_ready, det_p.static_graphs = True, True, True
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, T, 3, 224, 224, device="cuda", generator=g)
+    m = torch.ones(B, T, dtype=torch.bool, device="cuda")
+    m[5, 25:] = False
+    y = torch.arange(B, device="cuda") % 2
+    batches = [(x, m, y), (x.flip(0).contiguous(), m.flip(0).contiguous(), y.flip(0).contiguous()), (x * 0.5, m, y)] * 2
+    torch.cuda.synchronize()  # inputs_ready: every batch is complete in device memory before the loops
+
+    def run(det):
+        pos = det.decoder.positional_embedding
+        rest = [p for p in det.parameters() if p.requires_grad and p is not pos]
+        opt = torch.optim.SGD([{"params": [pos], "lr": 2.0}, {"params": rest, "lr": 0.01}], momentum=0.95, weight_decay=0.01)
+        losses = []
+        for xs, ms, ys in batches:
+            opt.zero_grad(set_to_none=True)
+            tl, _, other = det(xs, [ys], ms, train=True, single_task=0)
+            (tl[0].mean() + sum(other.values())).backward()
+            opt.step()
+            losses.append(tl[0].detach())
+        return losses
+
+    lp = run(det_p)
+    torch.cuda.synchronize()
+    le = run(det_e)
+    torch.cuda.synchronize()
+    moved = (det_e.decoder.positional_embedding - random_state_dict(cfg, T, seed=0)["decoder.positional_embedding"].cuda()).abs().max().item()
+    assert moved > 1e-2, "the positional embedding must really move in this test"
+    for step, (a, b) in enumerate(zip(lp, le)):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), f"step {step}: losses differ (max {float((a - b).abs().max()):.3e})"
+    for (n, pe), (_, pp) in zip(det_e.named_parameters(), det_p.named_parameters()):
+        assert torch.equal(pe, pp), n

@@ -100,6 +100,103 @@ def test_vitb16_cfg1_matches_reference(precision):
                 np.testing.assert_allclose(enc[l][key][i, rows].float().cpu().numpy(), g[f"enc{l}_{key}_f{fr}"], atol=tol, rtol=0)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_vitl14_matches_reference(precision):
+    """BASELINE.json configs[3]'s architecture (reference `src/clip/model.py:453-470`): ViT-L/14 = width 1024,
+    24 layers, 16 heads, 257 tokens, patch K = 588 (padded to 640), GEMM shapes N in {1024, 3072, 4096},
+    K in {1024, 4096}; 2 clips x 2 frames, layers 0, 2, .., 22 tapped.  fp32 path: logits within 1e-3 of the
+    reference's fp32 CPU result; bf16 path: documented bar."""
+    case = build_case("vitl14")
+    g = load_golden("vitl14")
+    det = make_detector(case, precision)
+    assert (det.encoder.width, det.encoder.layers, det.encoder.heads, det.encoder.tokens) == (1024, 24, 16, 257)
+    x, m, y = case["x"].cuda(), case["m"].cuda(), case["y"].cuda()
+    with torch.no_grad():
+        losses, logits = det(x, [y], m, single_task=0)
+        _, feats = det.predict(x, m, with_video_features=True)
+    err = np.abs(logits[0].cpu().numpy() - g["logits"]).max()
+    print(f"vitl14/{precision}: max |dlogit| = {err:.3e}")
+    tol = FP32_TOL if precision == "fp32" else BF16_TOL
+    assert err <= tol
+    np.testing.assert_allclose(feats["video"].cpu().numpy(), g["video_feature"], atol=2 * tol, rtol=0)
+    np.testing.assert_allclose(losses[0].cpu().numpy(), g["losses"], atol=2 * tol, rtol=0)
+    rows = list(g["slice_rows"])
+    enc = det.encoder(case["x"].flatten(0, 1)[[0, 3]].cuda())
+    tol_kv = 5e-4 if precision == "fp32" else 1e-1
+    for l in (0, 22):
+        for key in ("k", "v"):
+            for i, fr in enumerate((0, 3)):
+                np.testing.assert_allclose(enc[l][key][i, rows].float().cpu().numpy(), g[f"enc{l}_{key}_f{fr}"], atol=tol_kv, rtol=0)
+
+
+BF16_GOLDEN_CASES = ["small", "small14", "vitb16_cfg1", "vitl14", "tiny_adapter_nln", "tiny_adapter_ln", "tiny_adapter_gl"]
+
+
+@pytest.mark.parametrize("name", BF16_GOLDEN_CASES)
+def test_bf16_path_against_reference_bf16_run(name):
+    """The bf16 path next to the reference's OWN bf16 run (`logits_bf16`: the reference under
+    torch.autocast(bfloat16), which is what Accelerate's `mixed_precision: bf16` does).  On these seeded
+    random-weight cases the reference's bf16 run is itself 7e-3 .. 1e-1 away from its fp32 run (stored in the
+    fixtures, printed here), so two correct bf16 implementations cannot agree more tightly than that.  Bars:
+    (1) this path is no further from the reference's fp32 logits than the reference's own bf16 run is, plus
+    1e-2; (2) it is within that deviation + its own of the reference's bf16 logits (both printed)."""
+    case = build_case(name)
+    g = load_golden(name)
+    det = make_detector(case, "bf16")
+    x, m, y = case["x"].cuda(), case["m"].cuda(), case["y"].cuda()
+    with torch.no_grad():
+        _, logits = det(x, [y], m, single_task=0)
+    got = logits[0].cpu().numpy()
+    ref_dev = np.abs(g["logits_bf16"] - g["logits"]).max()
+    d32 = np.abs(got - g["logits"]).max()
+    d16 = np.abs(got - g["logits_bf16"]).max()
+    print(f"{name}: |hip_bf16 - ref_fp32| = {d32:.3e}   |hip_bf16 - ref_bf16| = {d16:.3e}   |ref_bf16 - ref_fp32| = {ref_dev:.3e}")
+    assert d32 <= ref_dev + 1e-2
+    assert d16 <= ref_dev + d32 + 1e-6
+    if name in ("vitb16_cfg1", "vitl14", "small", "small14"):
+        rows = list(g["slice_rows"])
+        n = case["B"] * case["T"]
+        enc = det.encoder(case["x"].flatten(0, 1)[[0, n - 1]].cuda())
+        for l in (case["layer_indices"][0], case["layer_indices"][-1]):
+            for key in ("k", "v"):
+                for i, fr in enumerate((0, n - 1)):
+                    mine = enc[l][key][i, rows].float().cpu().numpy()
+                    r32, r16 = g[f"enc{l}_{key}_f{fr}"], g[f"enc{l}_{key}_f{fr}_bf16"]
+                    assert np.abs(mine - r32).max() <= np.abs(r16 - r32).max() + 3e-2, (l, key, fr)
+
+
+def test_full_size_properties_vitl14_b8_t30():
+    """BASELINE configs[3] at full size (ViT-L/14, 8 clips x 30 frames, bf16): the size-independent properties of
+    `test_full_size_properties_b16_t30` on the large architecture's GEMM / attention shapes."""
+    from dfd_clip_amd.detector import Detector
+    from dfd_clip_amd.weights import random_state_dict
+    from tests.cases import make_config
+    cfg = make_config("ViT-L/14", decode_mode="stride", decode_stride=2)
+    B, T = 8, 30
+    det = Detector(cfg, T, None, precision="bf16")
+    det.load_state_dict(random_state_dict(cfg, T, seed=0))
+    det = det.cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(B, T, 3, 224, 224, device="cuda", generator=g)
+    m = torch.ones(B, T, dtype=torch.bool, device="cuda")
+    m[2, 17:] = False
+    with torch.no_grad():
+        base = det.predict(x, m)[0][0].clone()
+        assert torch.isfinite(base).all()
+        np.testing.assert_allclose(base.norm(dim=-1).cpu().numpy(), 5.0, atol=1e-4)
+        perm = torch.randperm(B, device="cuda", generator=g)
+        assert torch.equal(det.predict(x[perm].contiguous(), m[perm].contiguous())[0][0], base[perm]), "clips are not independent"
+        det.encoder.frame_chunk = 3 * T
+        assert torch.equal(det.predict(x, m)[0][0], base), "frame chunking changed the result"
+        det.encoder.frame_chunk = 0
+        x2 = x.clone()
+        x2[2, 17:] = 100.0 * torch.randn_like(x2[2, 17:])
+        assert torch.equal(det.predict(x2, m)[0][0], base), "a padded frame influenced its clip"
+        # the first clip alone through the same path: one clip does not depend on what else is in the batch
+        one = det.predict(x[:1].contiguous(), m[:1].contiguous())[0][0]
+        np.testing.assert_allclose(one.cpu().numpy(), base[:1].cpu().numpy(), atol=2e-2, rtol=0)
+
+
 def test_frame_chunking_is_bit_identical():
     case = build_case("small")
     det = make_detector(case, "bf16")

@@ -176,6 +176,94 @@ def test_gemm_large_m(capi, M, N):
         assert torch.isnan(cq2[:, :D].float()).all(), "the query block must not be written"
 
 
+# (N, K) of every encoder GEMM of ViT-B/16 and ViT-L/14 (reference clip/model.py:186, :197, :208-212, :277) plus
+# odd step counts; M >= 1024 puts them on the tuned kernel, whose steady-state K loop needs K/64 >= 3
+TUNED_SHAPES = [(768, 768), (2304, 768), (3072, 768), (768, 3072), (1024, 1024), (3072, 1024), (4096, 1024), (1024, 4096),
+                (768, 192), (1024, 640), (256, 320)]
+
+
+@pytest.mark.parametrize("N,K", TUNED_SHAPES)
+@pytest.mark.parametrize("M", [1024 + 256 * 7 + 77])
+def test_gemm_tuned_kernel_every_epilogue(capi, M, N, K):
+    """The tuned large-M bf16 kernel at the real K depths (its steady-state loop, odd and even step counts),
+    every epilogue, against fp64 on the same bf16-rounded operands: what is left is f32 accumulation order
+    and one rounding of the result (half a bf16 ulp = 2^-9; bar rtol 2^-8 + tiny atol)."""
+    g = torch.Generator(device="cuda").manual_seed(N * 7 + K)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    ref = a.double() @ w.double().T + bias.double()
+    RT = 2 ** -8
+    c = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    capi.gemm(a, w, c, bias, capi.EPI_BIAS)
+    assert capi.gemm_last_path() == 256, "this shape must run on the tuned kernel"
+    assert_close(c, ref, 1e-4, RT, "bias")
+    c.fill_(float("nan"))
+    capi.gemm(a, w, c, bias, capi.EPI_BIAS_QUICKGELU)
+    assert_close(c, ref * torch.sigmoid(1.702 * ref), 1e-4, RT, "quickgelu")
+    cf = torch.full((M, N), float("nan"), device="cuda")
+    capi.gemm(a, w, cf, bias, capi.EPI_BIAS)  # f32 store of the same product
+    assert_close(cf, ref, 1e-4, 1e-5, "bias, f32 out")
+    x0 = torch.randn(M, N, device="cuda", generator=g)
+    x = x0.clone()
+    capi.gemm(a, w, x, bias, capi.EPI_BIAS_RESIDUAL)  # f32 residual stream read-modify-write
+    assert_close(x, x0.double() + ref, 2e-4, 1e-5, "residual")
+    # adapter output: bf16 C = residual + acc + pos[frame % T] rounded once (no bias)
+    P_, T_ = 16, 3
+    res = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+    pos = torch.randn(T_, N, device="cuda", generator=g)
+    cr = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    capi.gemm(a, w, cr, None, capi.EPI_RESIDUAL_POS, pos=pos, tokens=P_ + 1, frames_per_clip=T_, residual=res)
+    frame = (torch.arange(M, device="cuda") // P_) % T_
+    assert_close(cr, res.double() + (ref - bias.double()) + pos[frame].double(), 1e-4, RT, "residual + pos")
+    if N % 768 == 0 or N % 1024 == 0:
+        if N in (2304, 3072) and N // 3 % 256 == 0:  # q | k | v projection with K/V export (+ temporal pos), CLS dropped
+            tokens, T = 7, 3
+            Mq = M // tokens * tokens
+            D = N // 3
+            tpos = torch.randn(T, D, device="cuda", generator=g)
+            ke = torch.full((Mq // tokens * (tokens - 1), D), float("nan"), device="cuda", dtype=torch.bfloat16)
+            ve = torch.full_like(ke, float("nan"))
+            cq = torch.full((Mq, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            capi.gemm(a[:Mq], w, cq, bias, capi.EPI_QKV_EXPORT, pos=tpos, k_export=ke, v_export=ve, tokens=tokens, frames_per_clip=T)
+            assert_close(cq, ref[:Mq], 1e-4, RT, "qkv")
+            fv = ref[:Mq].view(Mq // tokens, tokens, 3, D)
+            pos_f = tpos[torch.arange(Mq // tokens, device="cuda") % T].view(-1, 1, D).double()
+            assert_close(ke.view(-1, tokens - 1, D), fv[:, 1:, 1] + pos_f, 1e-4, RT, "k export")
+            assert_close(ve.view(-1, tokens - 1, D), fv[:, 1:, 2] + pos_f, 1e-4, RT, "v export")
+            ke2, ve2 = torch.full_like(ke, float("nan")), torch.full_like(ve, float("nan"))
+            cq2 = torch.full((Mq, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            capi.gemm(a[:Mq], w[D:], cq2[:, D:], bias[D:], capi.EPI_QKV_EXPORT, pos=tpos, k_export=ke2, v_export=ve2, tokens=tokens,
+                      frames_per_clip=T, qkv_first=1)
+            assert torch.equal(ke2, ke) and torch.equal(ve2, ve) and torch.equal(cq2[:, D:], cq[:, D:])
+
+
+@pytest.mark.parametrize("res,patch,width", [(224, 16, 768), (224, 14, 1024)])
+def test_patch_embed_tuned_kernel(capi, res, patch, width):
+    """PATCH_EMBED epilogue of the tuned kernel (M = frames*P >= 1024): conv1 + CLS row + positional embedding at
+    ViT-B/16's K = 768 and ViT-L/14's K = 588 padded to 640 (reference clip/model.py:277-291)."""
+    n = 8
+    P = (res // patch) ** 2
+    tokens = P + 1
+    g = torch.Generator(device="cuda").manual_seed(res + patch)
+    frames = torch.randn(n, 3, res, res, device="cuda", generator=g)
+    w = torch.randn(width, 3, patch, patch, device="cuda", generator=g) * (3 * patch * patch) ** -0.5
+    cls, pos = torch.randn(width, device="cuda", generator=g), torch.randn(tokens, width, device="cuda", generator=g)
+    fr, wr = frames.to(torch.bfloat16).double(), w.to(torch.bfloat16).double()
+    y = F.conv2d(fr.cpu(), wr.cpu(), None, stride=patch).reshape(n, width, -1).permute(0, 2, 1).cuda()
+    want = torch.cat([cls.view(1, 1, -1).expand(n, 1, width).double(), y], dim=1) + pos.double()
+    kreal = 3 * patch * patch
+    kpad = (kreal + 63) // 64 * 64
+    patches = torch.zeros((n * P + 255) // 256 * 256, kpad, device="cuda", dtype=torch.bfloat16)
+    capi.patchify(frames, patches, res, patch)
+    wp = torch.zeros(width, kpad, device="cuda")
+    wp[:, :kreal] = w.reshape(width, kreal)
+    x = torch.full((n * tokens, width), float("nan"), device="cuda")
+    capi.gemm(patches, wp.to(torch.bfloat16), x, None, capi.EPI_PATCH_EMBED, m=n * P, pos=pos, cls=cls, tokens=tokens)
+    assert capi.gemm_last_path() == 256
+    assert_close(x.view(n, tokens, width), want, 2e-4, 1e-5, "patch embed")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_qkv_export_layout(capi, dtype):
     """K/V column blocks land in [frames*P, D] with the CLS row dropped and pos[frame % T] added."""

@@ -154,3 +154,80 @@ def test_ema_teacher_update_and_schedule():
         else:
             torch.testing.assert_close(pt, before[n], atol=1e-6, rtol=0)
         assert not pt.requires_grad or pm.requires_grad
+
+
+def _clip_checkpoint(arch, dtype, seed=3):
+    """A synthetic CLIP checkpoint in the published key layout: `visual.`-prefixed ViT tower plus a few of the
+    text-tower keys `build_model` reads (reference clip/model.py:453-480)."""
+    from dfd_clip_amd.weights import _fill
+    rng = np.random.default_rng(seed)
+    sd = {"visual." + k: _fill(rng, k, shp).to(dtype) for k, shp in encoder_schema(arch).items()}
+    sd["text_projection"] = torch.zeros(8, 8, dtype=dtype)
+    sd["positional_embedding"] = torch.zeros(4, 8, dtype=dtype)
+    sd["logit_scale"] = torch.tensor(1.0)
+    return sd
+
+
+@pytest.mark.parametrize("arch", ["tiny", "small14"])
+def test_load_clip_visual_from_fp16_checkpoint(tmp_path, arch):
+    """`clip.load(path)` counterpart (reference clip/clip.py:121-122, :131-139; model.py:453-470): architecture
+    inferred from tensor shapes, `visual.` tower extracted, fp16 values widened to fp32 unchanged."""
+    from dfd_clip_amd.detector import load_clip_visual
+    build()
+    sd = _clip_checkpoint(arch, torch.float16)
+    path = str(tmp_path / "ckpt.pt")
+    torch.save(sd, path)
+    vit = load_clip_visual(path, "fp32")
+    res, patch, width, layers, heads, out_dim = ARCHS[arch]
+    assert (vit.input_resolution, vit.patch_size, vit.width, vit.layers, vit.heads, vit.output_dim) == (res, patch, width, layers, heads, out_dim)
+    got = vit.state_dict()
+    assert set(got) == {k[len("visual."):] for k in sd if k.startswith("visual.")}
+    for k, v in got.items():
+        assert v.dtype == torch.float32 and torch.equal(v, sd["visual." + k].float()), k
+
+
+def test_load_clip_visual_fp32_checkpoint_takes_the_fp16_round_trip(tmp_path):
+    """`convert_weights` (reference clip/model.py:429-450, :494) halves Conv/Linear parameters and `proj` before
+    the checkpoint is copied in; the reference's own attention class keeps `in_proj_*` in fp32, like LayerNorms
+    and embeddings.  An fp32 checkpoint therefore comes out rounded exactly there."""
+    from dfd_clip_amd.detector import load_clip_visual
+    build()
+    sd = _clip_checkpoint("tiny", torch.float32)
+    path = str(tmp_path / "ckpt32.pt")
+    torch.save({k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}, path)  # bare tower also loads
+    got = load_clip_visual(path, "bf16").state_dict()
+    rounded = 0
+    for k, v in got.items():
+        src = sd["visual." + k]
+        halved = k in ("conv1.weight", "proj") or any(t in k for t in (".out_proj.", ".mlp.c_fc.", ".mlp.c_proj."))
+        want = src.half().float() if halved else src
+        assert torch.equal(v, want), k
+        rounded += int(halved and not torch.equal(want, src))
+    assert rounded >= 4 * 2 + 2  # the round trip really changed those tensors
+    assert torch.equal(got["transformer.resblocks.0.attn.in_proj_weight"], sd["visual.transformer.resblocks.0.attn.in_proj_weight"])
+
+
+def test_load_clip_visual_rejects_torchscript_archive_with_instructions(tmp_path):
+    """The published ViT-B-16.pt is a TorchScript archive (reference clip/clip.py:127-130 tries torch.jit.load
+    first).  This loader executes nothing from a file, so it must say what the file is and how to convert it."""
+    from dfd_clip_amd.detector import load_clip_visual
+    build()
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(2))
+
+        def forward(self, x):
+            return x + self.w
+
+    path = str(tmp_path / "ViT-X.pt")
+    torch.jit.script(M()).save(path)
+    with pytest.raises(RuntimeError, match="TorchScript archive.*state_dict"):
+        load_clip_visual(path, "bf16")
+    bad = str(tmp_path / "resnet.pt")
+    torch.save({"visual.layer1.0.conv1.weight": torch.zeros(1)}, bad)
+    with pytest.raises(RuntimeError, match="no CLIP ViT visual tower"):
+        load_clip_visual(bad, "bf16")
+    with pytest.raises(RuntimeError, match="not found"):
+        load_clip_visual("ViT-Z/99", "bf16")

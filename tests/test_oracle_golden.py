@@ -13,7 +13,7 @@ from oracle import ref_cpu
 from tests.cases import CASES, build_case, load_golden, oracle_kwargs
 
 TOL = 2e-5
-FAST = [c for c in CASES if c != "vitb16_cfg1"]
+FAST = [c for c in CASES if c not in ("vitb16_cfg1", "vitl14")]
 
 
 @pytest.mark.parametrize("name", FAST)
@@ -105,3 +105,33 @@ def test_oracle_vitb16_cfg1():
         for key in ("k", "v"):
             for i, fr in enumerate((0, 15)):
                 np.testing.assert_allclose(enc[l][key][i, rows].numpy(), g[f"enc{l}_{key}_f{fr}"], atol=1e-4, rtol=0)
+
+
+def test_oracle_vitl14():
+    """BASELINE.json configs[3]'s architecture: ViT-L/14 (width 1024, 24 layers, 16 heads, 257 tokens), 2 clips x 2
+    frames, every other layer tapped (reference `src/clip/model.py:453-470`, `src/models.py:459`)."""
+    case = build_case("vitl14")
+    g = load_golden("vitl14")
+    kw = oracle_kwargs(case)
+    assert case["layer_indices"] == list(range(0, 24, 2)) == list(g["layer_indices"])
+    with torch.no_grad():
+        logits, feat = ref_cpu.detector_predict(case["sd"], case["x"], case["m"], **kw)
+        enc = ref_cpu.encoder_forward(case["sd"], case["x"].flatten(0, 1)[[0, 3]], case["heads"], case["patch"])
+    np.testing.assert_allclose(logits[0].numpy(), g["logits"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(feat.numpy(), g["video_feature"], atol=1e-4, rtol=0)
+    rows = list(g["slice_rows"])
+    for l in (0, 22):
+        for key in ("k", "v"):
+            for i, fr in enumerate((0, 3)):
+                np.testing.assert_allclose(enc[l][key][i, rows].numpy(), g[f"enc{l}_{key}_f{fr}"], atol=1e-4, rtol=0)
+
+
+def test_every_fixture_is_current():
+    """Every fixture was written by the current generator: it carries the training-contract keys and the
+    reference's bf16-autocast outputs."""
+    for name in CASES:
+        g = load_golden(name)
+        for key in ("logits", "losses", "video_feature", "train_task_loss", "step_losses", "logits_bf16", "video_feature_bf16"):
+            assert key in g.files, (name, key)
+        # the reference's own bf16 run stays within a few 1e-2 of its fp32 run on these norm-5 logits
+        assert np.abs(g["logits_bf16"] - g["logits"]).max() < 0.15, name
