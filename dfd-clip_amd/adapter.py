@@ -11,7 +11,9 @@ Kernel sequence per (layer, tensor) on the packed export `[N*P, D]`:
     dfd_gemm(BIAS, bias = NULL)                    a1 = kv · W0ᵀ           [N*P, x]
     dfd_adapter_norm_gelu                          a2 = GELU(LN(a1))        "nln": stats over (P, x); "ln"/"z0": over x
     dfd_gemm(RESIDUAL_POS)                         kv += a2 · W4ᵀ + pos[frame % T]   (in place, one rounding)
-Eval-mode semantics (dropout = identity).
+In `train()` mode with `config.dropout` > 0 the reference's two nn.Dropout layers act as there: p/10 (p/5 for
+`768-x-768`, none for `legacy-`) on a2, and p on a2 · W4ᵀ before the residual add (the GEMM epilogue draws the
+mask); masks are counter-based and regenerated in the backward (csrc/dropout.hpp).
 
 Training (`run`, with grad enabled and trainable parameters) goes through `_AdapterFn`: the forward is
 out of place and keeps a1; the backward takes dK/dV from the decoder's attention backward and runs
@@ -52,6 +54,9 @@ class CompInvAdapter(RuntimeStateMixin, nn.Module):
         self.ln_idx, self.out_idx, self.mode = _STRUCTS[self.struct]
         self.inner = int(config.adapter.struct.x)
         self.width = width
+        p = float(config.dropout) if "dropout" in config else 0.0
+        self.drop_outer = p  # every struct ends in nn.Dropout(p) (models.py:807, :820, :836, :852, :864)
+        self.drop_inner = 0.0 if self.struct == "legacy-768-x-768" else (p / 5 if self.struct == "768-x-768" else p / 10)
         self.residual = True
         self.n_layers = len(detector.layer_indices)
         for i in range(self.n_layers):
@@ -98,14 +103,24 @@ class CompInvAdapter(RuntimeStateMixin, nn.Module):
             self._prep = (key, w)
         return self._prep[1]
 
-    def run(self, k_raw, v_raw, num_frames, temporal_pos):
+    def run(self, k_raw, v_raw, num_frames, temporal_pos, drop_rng=None):
         """(k, v) = adapter(raw export) + pos.  In place without autograd; out of place through
-        `_AdapterFn` when gradients can flow to the adapter's parameters."""
+        `_AdapterFn` when gradients can flow to the adapter's parameters.  `drop_rng`: this step's
+        dropout state (device int64 {seed, step}) in train mode, None = no dropout."""
         names = [n for n, p in self.named_parameters()]
         params = [p for n, p in self.named_parameters()]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            return _AdapterFn.apply(self, k_raw, v_raw, num_frames, temporal_pos, names, *params)
-        return self.apply_packed(k_raw, v_raw, num_frames, temporal_pos)
+            return _AdapterFn.apply(self, k_raw, v_raw, num_frames, temporal_pos, names, drop_rng, *params)
+        return self.apply_packed(k_raw, v_raw, num_frames, temporal_pos, drop_rng)
+
+    def _drops(self, drop_rng, i, jj):
+        """(inner, outer) dropout descriptors of layer i, tensor jj (0 = k, 1 = v); None where inactive."""
+        if drop_rng is None:
+            return None, None
+        base = 1000 + 4 * (2 * i + jj)
+        inner = capi.Dropout(drop_rng, base, self.drop_inner) if self.drop_inner > 0 else None
+        outer = capi.Dropout(drop_rng, base + 1, self.drop_outer) if self.drop_outer > 0 else None
+        return inner, outer
 
     def _stage_weights(self, w, act):
         out = {}
@@ -117,7 +132,7 @@ class CompInvAdapter(RuntimeStateMixin, nn.Module):
                                w[pre + f"{self.out_idx}.weight"].to(act).contiguous())
         return out
 
-    def _forward_train(self, w, k_raw, v_raw, num_frames, temporal_pos):
+    def _forward_train(self, w, k_raw, v_raw, num_frames, temporal_pos, drop_rng=None):
         act = k_raw.dtype
         sw = self._stage_weights(w, act)
         L, rows, D = k_raw.shape
@@ -132,13 +147,16 @@ class CompInvAdapter(RuntimeStateMixin, nn.Module):
         for i in range(L):
             for jj, (j, src, dst) in enumerate((("k", k_raw, k_out), ("v", v_raw, v_out))):
                 w0, lw, lb, w4 = sw[(i, j)]
+                inner, outer = self._drops(drop_rng, i, jj)
                 capi.gemm(src[i], w0, a1_all[i, jj], None, capi.EPI_BIAS)
                 capi.adapter_norm_gelu(a1_all[i, jj], a2, lw, lb, frames, P, x, joint)
+                if inner is not None:
+                    capi.dropout(a2, a2, inner)
                 capi.gemm(a2, w4, dst[i], None, capi.EPI_RESIDUAL_POS, pos=temporal_pos, tokens=P + 1, frames_per_clip=num_frames,
-                          residual=src[i])
+                          residual=src[i], drop=outer)
         return k_out, v_out, a1_all
 
-    def _backward_train(self, w, k_raw, v_raw, a1_all, dk, dv):
+    def _backward_train(self, w, k_raw, v_raw, a1_all, dk, dv, drop_rng=None):
         act = k_raw.dtype
         sw = self._stage_weights(w, act)
         L, rows, D = k_raw.shape
@@ -154,17 +172,28 @@ class CompInvAdapter(RuntimeStateMixin, nn.Module):
         ws_ab = torch.empty(nb // 4 + 64, **f32)
         ws_ln = torch.empty(capi.adapter_norm_gelu_bwd_workspace_bytes(frames, P, x, joint) // 4 + 4, **f32)
         grads = {}
+        d_masked = None
         for i in range(L):
             for jj, (j, src, dout) in enumerate((("k", k_raw, dk), ("v", v_raw, dv))):
                 pre = f"l{i}_{j}."
                 w0, lw, lb, w4 = sw[(i, j)]
-                d_o = dout[i].to(act) if dout.dtype != act else dout[i]
+                inner, outer = self._drops(drop_rng, i, jj)
+                if outer is not None:  # gradient entering the dropped a2 · W4ᵀ: same mask, same scale
+                    if d_masked is None:
+                        d_masked = torch.empty(rows, D, device=dev, dtype=act)
+                    d_o = capi.dropout(dout[i], d_masked, outer)
+                else:
+                    d_o = dout[i].to(act) if dout.dtype != act else dout[i]
                 a1 = a1_all[i, jj]
                 capi.adapter_norm_gelu(a1, a2, lw, lb, frames, P, x, joint)
+                if inner is not None:
+                    capi.dropout(a2, a2, inner)
                 dw4 = torch.empty(D, x, **f32)
                 capi.gemm_at_b(d_o, a2, dw4, ws_ab)
                 w4t = w[pre + f"{self.out_idx}.weight"].float().t().contiguous().to(act)  # [x, D]: dA2 = dOut @ W4 as A @ (W4^T)^T
                 capi.gemm(d_o, w4t, da2, None, capi.EPI_BIAS)
+                if inner is not None:
+                    capi.dropout(da2, da2, inner)
                 dlw, dlb = torch.empty_like(lw), torch.empty_like(lb)
                 capi.adapter_norm_gelu_bwd(a1, da2, da1, lw, lb, dlw, dlb, ws_ln, frames, P, x, joint)
                 dw0 = torch.empty(x, D, **f32)
@@ -174,7 +203,7 @@ class CompInvAdapter(RuntimeStateMixin, nn.Module):
         return grads
 
     @torch.no_grad()
-    def apply_packed(self, k_all, v_all, num_frames, temporal_pos):
+    def apply_packed(self, k_all, v_all, num_frames, temporal_pos, drop_rng=None):
         """In place on the packed exports [L, N*P, D] (raw encoder K/V, no positional embedding yet):
         afterwards they hold adapter(kv) + pos, i.e. exactly what the decoder attends to."""
         if not k_all.is_cuda:
@@ -188,11 +217,15 @@ class CompInvAdapter(RuntimeStateMixin, nn.Module):
         a2 = torch.empty(rows, x, device=k_all.device, dtype=act) if self.mode == 2 else a1
         joint = self.mode
         for i in range(L):
-            for j, t in (("k", k_all), ("v", v_all)):
+            for jj, (j, t) in enumerate((("k", k_all), ("v", v_all))):
                 w0, lw, lb, w4 = w[(i, j)]
+                inner, outer = self._drops(drop_rng, i, jj)
                 capi.gemm(t[i], w0, a1, None, capi.EPI_BIAS)
                 capi.adapter_norm_gelu(a1, a2, lw, lb, frames, P, x, joint)
-                capi.gemm(a2, w4, t[i], None, capi.EPI_RESIDUAL_POS, pos=temporal_pos, tokens=P + 1, frames_per_clip=num_frames)
+                if inner is not None:
+                    capi.dropout(a2, a2, inner)
+                capi.gemm(a2, w4, t[i], None, capi.EPI_RESIDUAL_POS, pos=temporal_pos, tokens=P + 1, frames_per_clip=num_frames,
+                          drop=outer)
         return k_all, v_all
 
 
@@ -200,10 +233,10 @@ class _AdapterFn(torch.autograd.Function):
     """autograd node around the adapter's HIP forward / backward.  Outputs (k, v) = adapter(raw) + pos."""
 
     @staticmethod
-    def forward(ctx, adapter, k_raw, v_raw, num_frames, temporal_pos, names, *params):
+    def forward(ctx, adapter, k_raw, v_raw, num_frames, temporal_pos, names, drop_rng, *params):
         w = {n: p.detach() for n, p in zip(names, params)}
-        k_out, v_out, a1_all = adapter._forward_train(w, k_raw, v_raw, num_frames, temporal_pos)
-        ctx.adapter, ctx.w, ctx.names = adapter, w, names
+        k_out, v_out, a1_all = adapter._forward_train(w, k_raw, v_raw, num_frames, temporal_pos, drop_rng)
+        ctx.adapter, ctx.w, ctx.names, ctx.drop_rng = adapter, w, names, drop_rng
         ctx.after_backward, adapter._after_backward = adapter._after_backward, None
         ctx.saved = (k_raw, v_raw, a1_all)
         ctx.req = [p.requires_grad for p in params]
@@ -212,8 +245,8 @@ class _AdapterFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dk, dv):
         k_raw, v_raw, a1_all = ctx.saved
-        grads = ctx.adapter._backward_train(ctx.w, k_raw, v_raw, a1_all, dk.contiguous(), dv.contiguous())
+        grads = ctx.adapter._backward_train(ctx.w, k_raw, v_raw, a1_all, dk.contiguous(), dv.contiguous(), ctx.drop_rng)
         out = [grads.get(nm) if rq else None for nm, rq in zip(ctx.names, ctx.req)]
         if ctx.after_backward is not None:
             ctx.after_backward()
-        return (None, None, None, None, None, None, *out)
+        return (None, None, None, None, None, None, None, *out)

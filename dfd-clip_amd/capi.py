@@ -6,7 +6,7 @@ raises.  Tensors are passed as raw device pointers; every call enqueues on
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 import torch
 
@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT, EPI_RESIDUAL_POS = range(6)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -26,7 +26,28 @@ class DfdError(RuntimeError):
 
 class GemmExtra(Structure):
     _fields_ = [("pos", c_void_p), ("cls", c_void_p), ("k_export", c_void_p), ("v_export", c_void_p),
-                ("tokens", c_int32), ("frames_per_clip", c_int32), ("residual", c_void_p), ("qkv_first", c_int32)]
+                ("tokens", c_int32), ("frames_per_clip", c_int32), ("residual", c_void_p), ("qkv_first", c_int32),
+                ("drop_rng", c_void_p), ("drop_site", c_uint32), ("drop_p", c_float)]
+
+
+class DropoutDesc(Structure):
+    _fields_ = [("rng_state", c_void_p), ("site", c_uint32), ("p", c_float)]
+
+
+class Dropout:
+    """One dropout layer of one step: `rng` = device int64[2] {seed, step}, `site` = which layer, `p`."""
+    __slots__ = ("rng", "site", "p")
+
+    def __init__(self, rng, site, p):
+        assert rng.is_cuda and rng.dtype == torch.int64 and rng.numel() == 2 and 0.0 <= p < 1.0
+        self.rng, self.site, self.p = rng, int(site), float(p)
+
+    def desc(self):
+        return DropoutDesc(self.rng.data_ptr(), self.site, self.p)
+
+
+def _drop(d):
+    return ctypes.byref(d.desc()) if d is not None and d.p > 0 else None
 
 
 # name -> (restype, argtypes); mirrors include/dfdclip.h one to one
@@ -34,6 +55,7 @@ SIGNATURES = {
     "dfd_last_error": (c_char_p, []),
     "dfd_abi_version": (c_int, []),
     "dfd_gemm_last_path": (c_int, []),
+    "dfd_dropout": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, POINTER(DropoutDesc), c_void_p]),
     "dfd_device_check": (c_int, []),
     "dfd_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_float, c_void_p]),
     "dfd_add_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
@@ -71,11 +93,11 @@ SIGNATURES = {
     "dfd_transpose_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dfd_layernorm_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_float, c_int, c_void_p]),
-    "dfd_quickgelu": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dfd_quickgelu": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(DropoutDesc), c_void_p]),
     "dfd_head_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_void_p]),
     "dfd_head_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                             c_int, c_float, c_void_p]),
+                             c_int, c_float, POINTER(DropoutDesc), c_void_p]),
 }
 
 _lib = None
@@ -208,7 +230,7 @@ def profile_gemm_collect():
 
 
 def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_export=None, v_export=None, tokens=0,
-         frames_per_clip=0, residual=None, qkv_first=0):
+         frames_per_clip=0, residual=None, qkv_first=0, drop=None):
     """c = epilogue(a[M,K] @ w[N,K]^T).  `m` limits the rows used (buffers may be over-allocated)."""
     _dev(a, w, c, bias, pos, cls, k_export, v_export, residual)
     assert a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1 and c.stride(1) == 1
@@ -216,8 +238,10 @@ def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_ex
     N, K = w.shape
     assert a.shape[1] == K
     assert residual is None or (residual.dtype == c.dtype and residual.stride(0) == c.stride(0))
+    assert drop is None or epilogue == EPI_RESIDUAL_POS
     extra = GemmExtra(_ptr(pos).value, _ptr(cls).value, _ptr(k_export).value, _ptr(v_export).value, tokens, frames_per_clip,
-                      _ptr(residual).value, qkv_first)
+                      _ptr(residual).value, qkv_first, drop.rng.data_ptr() if drop is not None and drop.p > 0 else None,
+                      drop.site if drop is not None else 0, drop.p if drop is not None else 0.0)
     timed = _profile["epilogue"] == epilogue
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -354,13 +378,22 @@ def decoder_attn_modes_bwd(scores, v, dmix, modes, dwv_ws, dscores, B, T, patche
     return dscores
 
 
-def head_fwd(x, gamma, beta, proj, feat, raw, logits, eps=1e-5):
+def head_fwd(x, gamma, beta, proj, feat, raw, logits, eps=1e-5, drop=None):
     _dev(x, gamma, beta, proj, feat, raw, logits)
     B, D = x.shape
-    assert proj.is_contiguous() and proj.shape[0] == D
+    assert proj.is_contiguous() and proj.shape[0] == D and feat.is_contiguous()
     _check(load_library().dfd_head_fwd(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(proj), _ptr(feat), _ptr(raw),
-                                       _ptr(logits), B, D, proj.shape[1], eps, _stream()), "dfd_head_fwd")
+                                       _ptr(logits), B, D, proj.shape[1], eps, _drop(drop), _stream()), "dfd_head_fwd")
     return logits
+
+
+def dropout(x, out, drop):
+    """out = dropout(x) elementwise (element index = flat position); also its own backward.  In place allowed."""
+    _dev(x, out)
+    assert x.is_contiguous() and out.is_contiguous() and x.numel() == out.numel() and drop is not None
+    _check(load_library().dfd_dropout(_ptr(x), _DTYPE[x.dtype], _ptr(out), _DTYPE[out.dtype], x.numel(),
+                                      ctypes.byref(drop.desc()), _stream()), "dfd_dropout")
+    return out
 
 
 # ---- decoder backward ------------------------------------------------------------------------
@@ -410,10 +443,10 @@ def layernorm_bwd(x, gamma, dy, dx, dgamma, dbeta, xhat_ws, accumulate_dx=False,
     return dx
 
 
-def quickgelu(u, out, du=None):
+def quickgelu(u, out, du=None, drop=None):
     _dev(u, out, du)
     assert u.is_contiguous() and out.is_contiguous() and (du is None or du.is_contiguous())
-    _check(load_library().dfd_quickgelu(_ptr(u), _ptr(du), _ptr(out), u.numel(), _stream()), "dfd_quickgelu")
+    _check(load_library().dfd_quickgelu(_ptr(u), _ptr(du), _ptr(out), u.numel(), _drop(drop), _stream()), "dfd_quickgelu")
     return out
 
 

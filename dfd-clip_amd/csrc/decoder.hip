@@ -14,7 +14,7 @@
 // dfd_linear_rows — y[B,N] = x[B,K]·W[N,K]ᵀ + b: one wave per output column streams the weight
 //   row once per 8 clips; x stays L1/L2 resident.
 // dfd_head_fwd — ln_post + projection + 5·z/(‖z‖+1e-10).
-#include "common.hpp"
+#include "dropout.hpp"
 
 namespace {
 
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ proj,
                                                    float* __restrict__ feat, float* __restrict__ raw,
-                                                   float* __restrict__ logits, int D, int out_dim, float eps) {
+                                                   float* __restrict__ logits, int D, int out_dim, float eps, DfdDrop drop) {
   extern __shared__ float sh[];  // [D] feature, [out_dim] z, [8] scratch
   float* f = sh;
   float* z = sh + D;
@@ -349,7 +349,8 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
   __syncthreads();
   const float rstd = rsqrtf((scratch[0] + scratch[1] + scratch[2] + scratch[3]) / (float)D + eps);
   for (int c = tid; c < D; c += 256) {
-    const float o = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+    float o = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+    o = dfd_drop_one(drop, (uint64_t)b * D + c, o);  // drop_post (models.py:342): the projection sees the dropped feature
     f[c] = o;
     feat[(int64_t)b * D + c] = o;
   }
@@ -622,13 +623,15 @@ extern "C" int dfd_linear_rows_t(const float* x, int64_t ldx, const float* Wt, c
 
 extern "C" int dfd_head_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* proj,
                             float* video_feature, float* raw_logits, float* logits, int B, int D, int out_dim,
-                            float eps, void* stream) {
+                            float eps, const dfd_dropout_t* drop_post, void* stream) {
   DFD_REQUIRE(x && gamma && beta && proj && video_feature && raw_logits && logits, "dfd_head_fwd: null pointer");
+  DFD_REQUIRE(!drop_post || (drop_post->p >= 0.f && drop_post->p < 1.f && (drop_post->p == 0.f || drop_post->rng_state)),
+              "dfd_head_fwd: bad dropout descriptor");
   DFD_REQUIRE(B >= 0 && D > 0 && out_dim > 0 && out_dim <= 4096 && ldx >= D, "dfd_head_fwd: bad shape");
   if (B == 0) return DFD_OK;
   const size_t lds = (size_t)(D + out_dim + 8) * sizeof(float);
   hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), x, ldx, gamma, beta, proj,
-                     video_feature, raw_logits, logits, D, out_dim, eps);
+                     video_feature, raw_logits, logits, D, out_dim, eps, dfd_make_drop(drop_post));
   DFD_CHECK_LAUNCH("dfd_head_fwd");
   return DFD_OK;
 }

@@ -10,7 +10,7 @@
 //   dK / dV (they are only materialised when the caller asks for them: adapter training).
 // dfd_linear_rows_bwd_weight, dfd_transpose_f32, dfd_layernorm_bwd, dfd_quickgelu, dfd_head_bwd —
 //   the [B, D]-row pieces of the backward.
-#include "common.hpp"
+#include "dropout.hpp"
 
 namespace {
 
@@ -360,12 +360,14 @@ __global__ void layernorm_bwd_cols_kernel(const float* __restrict__ dy, int64_t 
 }
 
 // du == nullptr: out = g(u);  else out = du · g'(u), g(u) = u·σ(1.702u)
-__global__ void quickgelu_kernel(const float* __restrict__ u, const float* __restrict__ du, float* __restrict__ out, int64_t n) {
+__global__ void quickgelu_kernel(const float* __restrict__ u, const float* __restrict__ du, float* __restrict__ out, int64_t n,
+                                 DfdDrop d) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float x = u[i];
   const float sg = 1.0f / (1.0f + __expf(-1.702f * x));
-  out[i] = du ? du[i] * (sg + 1.702f * x * sg * (1.0f - sg)) : x * sg;
+  const float r = du ? du[i] * (sg + 1.702f * x * sg * (1.0f - sg)) : x * sg;
+  out[i] = dfd_drop_one(d, (uint64_t)i, r);  // y = m·s·g(u); dL/du = m·s·dL/dy·g'(u)
 }
 
 // Head backward: logits = 5 z/(‖z‖+ε), z = f·P, f = LN(x).  One workgroup per clip computes dz and
@@ -526,11 +528,12 @@ extern "C" int dfd_layernorm_bwd(const float* x, int64_t ldx, const float* gamma
   return DFD_OK;
 }
 
-extern "C" int dfd_quickgelu(const float* u, const float* du, float* out, int64_t n, void* stream) {
+extern "C" int dfd_quickgelu(const float* u, const float* du, float* out, int64_t n, const dfd_dropout_t* drop, void* stream) {
   DFD_REQUIRE(u && out && n >= 0, "dfd_quickgelu: bad arguments");
+  DFD_REQUIRE(!drop || (drop->p >= 0.f && drop->p < 1.f && (drop->p == 0.f || drop->rng_state)), "dfd_quickgelu: bad dropout descriptor");
   if (n == 0) return DFD_OK;
   hipLaunchKernelGGL(quickgelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), u, du,
-                     out, n);
+                     out, n, dfd_make_drop(drop));
   DFD_CHECK_LAUNCH("dfd_quickgelu");
   return DFD_OK;
 }

@@ -47,7 +47,7 @@ __device__ __forceinline__ void epilogue_elem(const GemmArgs& a, int64_t m, int 
     const float p = a.pos ? a.pos[(frame % a.frames_per_clip) * a.N + n] : 0.f;
     CT* c = static_cast<CT*>(a.C) + m * a.ldc + n;
     const CT* rsd = a.residual ? static_cast<const CT*>(a.residual) + m * a.ldc + n : c;
-    *c = from_f32<CT>(to_f32(*rsd) + acc + p);
+    *c = from_f32<CT>(to_f32(*rsd) + dfd_drop_one(a.drop, (uint64_t)m * a.N + n, acc) + p);
   } else if constexpr (EPI == DFD_EPI_QKV_EXPORT) {
     const float v = acc + (a.bias ? a.bias[n] : 0.f);
     store_c<CT>(a.C, m * a.ldc + n, v);
@@ -316,6 +316,11 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
     a.residual = epilogue == DFD_EPI_RESIDUAL_POS ? extra->residual : nullptr;
     a.tokens = extra->tokens; a.frames_per_clip = extra->frames_per_clip > 0 ? extra->frames_per_clip : 1;
     a.qkv_first = epilogue == DFD_EPI_QKV_EXPORT ? extra->qkv_first : 0;
+    if (epilogue == DFD_EPI_RESIDUAL_POS && extra->drop_rng && extra->drop_p > 0.f) {
+      DFD_REQUIRE(extra->drop_p < 1.f, "dfd_gemm: drop_p=%f", (double)extra->drop_p);
+      const dfd_dropout_t dd{extra->drop_rng, extra->drop_site, extra->drop_p};
+      a.drop = dfd_make_drop(&dd);
+    }
   }
   if (M == 0) return DFD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -333,11 +333,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
             p0 = *reinterpret_cast<const f32x4*>(pr);
             p1 = *reinterpret_cast<const f32x4*>(pr + 4);
           }
+          float dv[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { dv[e] = d0[e]; dv[4 + e] = d1[e]; }
+          dfd_drop_eight(a.drop, (uint64_t)m * a.N + nb + c * 8, dv);  // the adapter's last nn.Dropout, before the residual add
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            o[e] = (bf16_t)((float)old[e] + d0[e] + p0[e]);
-            o[4 + e] = (bf16_t)((float)old[4 + e] + d1[e] + p1[e]);
+            o[e] = (bf16_t)((float)old[e] + dv[e] + p0[e]);
+            o[4 + e] = (bf16_t)((float)old[4 + e] + dv[4 + e] + p1[e]);
           }
           *cp = o;
         }

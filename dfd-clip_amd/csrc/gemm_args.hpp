@@ -1,6 +1,6 @@
 // Argument block shared by the GEMM kernels (gemm.hip: general shapes; gemm256.hip: tuned bf16).
 #pragma once
-#include "common.hpp"
+#include "dropout.hpp"
 
 struct GemmArgs {
   const void* A;
@@ -15,6 +15,7 @@ struct GemmArgs {
   int64_t lda, ldw, ldc, M;
   int N, K, tokens, frames_per_clip;
   int qkv_first;  // QKV_EXPORT: first column block present (0 = q, 1 = k)
+  DfdDrop drop;   // RESIDUAL_POS: dropout on the accumulator (element index row*N + col); thr16 == 0: none
 };
 
 // tuned bf16 kernel (gemm256.hip): 0 = launched, <0 = error, 1 = shape not eligible

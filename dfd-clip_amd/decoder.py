@@ -4,7 +4,9 @@ Host-side mirror of the reference's `Decoder` (reference `src/models.py:272-361`
 block (`:149-176`), stack (`:232-269`) and two-branch attention (`:81-146`): same parameter
 names and shapes, same `forward(kvs, m) -> (task_logits, video_feature)` contract.  One
 learned CLS query per clip attends to the T*P exported keys/values of one encoder layer per
-block.  Eval-mode semantics (dropout = identity).
+block.  In `train()` mode with `config.dropout` > 0 the reference's nn.Dropout layers act as there: drop_pre
+after ln_pre (`:337`), one in every block's MLP after QuickGELU (`:163`), drop_post after ln_post (`:342`);
+masks are counter-based, drawn inside the kernels and regenerated in the backward (csrc/dropout.hpp).
 
 Kernel sequence per block, rows = clips (B), everything f32 except the K/V stream:
   LayerNorm -> dfd_linear_rows(in_proj) -> dfd_decoder_attn_fwd (streams K and V once)
@@ -66,6 +68,7 @@ class Decoder(RuntimeStateMixin, nn.Module):
         width, heads = enc.width, enc.heads
         self.width, self.heads, self.num_frames = width, heads, num_frames
         self.op_mode = config.op_mode
+        self.dropout_p = float(config.dropout) if "dropout" in config else 0.0
         self.out_dims = list(config.out_dim)
         self.layer_indices = list(detector.layer_indices)
         scale = width ** -0.5
@@ -174,24 +177,34 @@ class Decoder(RuntimeStateMixin, nn.Module):
         # enough workgroups to fill 256 CUs a few times over, few enough partial states to merge cheaply
         return max(1, min(S // 64, max(1, 768 // max(B, 1))))
 
-    def run(self, kvs, m):
+    def _drop(self, drop_rng, site):
+        """Dropout descriptor of one site of this step (0 = drop_pre, 1 + i = block i's MLP, 250 + j = drop_post of
+        head j), or None."""
+        if drop_rng is None or self.dropout_p <= 0:
+            return None
+        return capi.Dropout(drop_rng, site, self.dropout_p)
+
+    def run(self, kvs, m, drop_rng=None):
         """-> (raw logits list, video_feature, normalised logits list).  With grad enabled and any
-        trainable parameter, goes through `_DecoderFn` so `loss.backward()` reaches the parameters."""
+        trainable parameter, goes through `_DecoderFn` so `loss.backward()` reaches the parameters.
+        `drop_rng`: this step's dropout state (device int64 {seed, step}) in train mode, None = no dropout."""
         k_all, v_all, mask, B, T, P = self._unpack(kvs, m)
+        if self.dropout_p <= 0:
+            drop_rng = None
         if self._param_list is None:  # the module tree is static: walk it once, not every step
             self._param_list = list(self.named_parameters())
         names = [n for n, p in self._param_list]
         params = [p for n, p in self._param_list]
         if torch.is_grad_enabled() and (any(p.requires_grad for p in params) or k_all.requires_grad):
-            out = _DecoderFn.apply(self, k_all, v_all, mask, (B, T, P), names, *params)
+            out = _DecoderFn.apply(self, k_all, v_all, mask, (B, T, P), names, drop_rng, *params)
             n = len(self.out_dims)
             return list(out[1:1 + n]), out[0], list(out[1 + n:1 + 2 * n])
         w = {n: p.detach() for n, p in zip(names, params)}
-        raws, feat, outs, _ = self._forward_kernels(w, k_all, v_all, mask, B, T, P, save=False)
+        raws, feat, outs, _ = self._forward_kernels(w, k_all, v_all, mask, B, T, P, save=False, drop_rng=drop_rng)
         return raws, feat, outs
 
     # ---- forward on HIP kernels --------------------------------------------------------------
-    def _forward_kernels(self, w, k_all, v_all, mask, B, T, P, save):
+    def _forward_kernels(self, w, k_all, v_all, mask, B, T, P, save, drop_rng=None):
         dev = k_all.device
         D, H, L = self.width, self.heads, k_all.shape[0]
         f32 = dict(device=dev, dtype=torch.float32)
@@ -207,7 +220,9 @@ class Decoder(RuntimeStateMixin, nn.Module):
         x0 = g("class_embedding").view(1, D).repeat(B, 1).contiguous()
         x = new(B, D)
         capi.layernorm(x0, g("ln_pre.weight"), g("ln_pre.bias"), x)
-        saved = dict(x0=x0, blocks=[])
+        if self._drop(drop_rng, 0) is not None:
+            capi.dropout(x, x, self._drop(drop_rng, 0))  # drop_pre (models.py:337)
+        saved = dict(x0=x0, blocks=[], drop_rng=drop_rng)
         xs = []  # per-block outputs, read by the per-layer heads of `global_prediction`
         mode_ws = None
         h, q, mix, stats, u = new(B, D), new(B, 2 * D), new(B, D), new(B, H, 2), new(B, 4 * D)
@@ -229,7 +244,7 @@ class Decoder(RuntimeStateMixin, nn.Module):
                 h2, u_pre, uu = new(B, D), new(B, 4 * D), new(B, 4 * D)
                 capi.layernorm(x_mid, g(pre + "ln_2.weight"), g(pre + "ln_2.bias"), h2)
                 lin(h2, pre + "mlp.c_fc.", u_pre)
-                capi.quickgelu(u_pre, uu)
+                capi.quickgelu(u_pre, uu, drop=self._drop(drop_rng, 1 + i))
                 x = x_mid.clone()
                 lin(uu, pre + "mlp.c_proj.", x, capi.EPI_BIAS_RESIDUAL)
                 saved["blocks"].append(dict(x_in=x_in, h1=h1, q=q, mix=mix, mix_s=mix_s, stats=stats, x_mid=x_mid, h2=h2,
@@ -246,6 +261,8 @@ class Decoder(RuntimeStateMixin, nn.Module):
                 lin(mix, pre + "attn.out_proj.", x, capi.EPI_BIAS_RESIDUAL)
                 capi.layernorm(x, g(pre + "ln_2.weight"), g(pre + "ln_2.bias"), h)
                 lin(h, pre + "mlp.c_fc.", u, capi.EPI_BIAS_QUICKGELU)
+                if self._drop(drop_rng, 1 + i) is not None:  # train() under no_grad: same masks as the autograd path
+                    capi.dropout(u, u, self._drop(drop_rng, 1 + i))
                 lin(u, pre + "mlp.c_proj.", x, capi.EPI_BIAS_RESIDUAL)
             if self.global_prediction:
                 xs.append(x if save else x.clone())
@@ -264,7 +281,8 @@ class Decoder(RuntimeStateMixin, nn.Module):
                 z = torch.zeros(B, od, **f32)
                 for j, l in enumerate(self.layer_indices):
                     fj, rj, tmp = new(B, D), new(B, od), new(B, od)
-                    capi.head_fwd(xs[j], g("ln_post.weight"), g("ln_post.bias"), g(f"proj{i}x{od}_L{l}"), fj, rj, tmp)
+                    capi.head_fwd(xs[j], g("ln_post.weight"), g("ln_post.bias"), g(f"proj{i}x{od}_L{l}"), fj, rj, tmp,
+                                  drop=self._drop(drop_rng, 250 + j))
                     feat[:, j] = fj
                     z += cw[j] * rj
                 raws.append(z)
@@ -274,7 +292,8 @@ class Decoder(RuntimeStateMixin, nn.Module):
             feat = new(B, D)
             for i, od in enumerate(self.out_dims):
                 raw, logits = new(B, od), new(B, od)
-                capi.head_fwd(x, g("ln_post.weight"), g("ln_post.bias"), g(f"proj{i}x{od}"), feat, raw, logits)
+                capi.head_fwd(x, g("ln_post.weight"), g("ln_post.bias"), g(f"proj{i}x{od}"), feat, raw, logits,
+                              drop=self._drop(drop_rng, 250))
                 raws.append(raw)
                 outs.append(logits)
         saved["x_last"] = x
@@ -295,6 +314,7 @@ class Decoder(RuntimeStateMixin, nn.Module):
         grads = {}
         xhat = new(B, D)
         lws = self._lin_ws(B, dev)
+        drop_rng = saved.get("drop_rng")
 
         def lin_bwd(pre, dy, x_act, want_dx=True):
             """dy [B,N] -> grads of Linear `pre` (weight [N,K], bias) and, optionally, dx [B,K]."""
@@ -335,6 +355,8 @@ class Decoder(RuntimeStateMixin, nn.Module):
             for j in range(L):
                 dxj, dgam, dbet = new(B, D), new(D), new(D)
                 dfj = dfeat_layers[j] if dfeat_layers[j] is not None else torch.zeros(B, D, **f32)
+                if self._drop(drop_rng, 250 + j) is not None:  # video_feature_j = drop_post(ln_post(x_j))
+                    capi.dropout(dfj, dfj, self._drop(drop_rng, 250 + j))
                 capi.layernorm_bwd(saved["xs"][j], g("ln_post.weight"), dfj, dxj, dgam, dbet, xhat)
                 head_dx.append(dxj)
                 dgam_t += dgam
@@ -362,6 +384,8 @@ class Decoder(RuntimeStateMixin, nn.Module):
                 dfeat = dfi
             if dfeat is None:
                 dfeat = torch.zeros(B, D, **f32)
+            if self._drop(drop_rng, 250) is not None:  # video_feature = drop_post(ln_post(x))
+                capi.dropout(dfeat, dfeat, self._drop(drop_rng, 250))
             dx = new(B, D)
             dgam, dbet = new(D), new(D)
             capi.layernorm_bwd(x_last, g("ln_post.weight"), dfeat, dx, dgam, dbet, xhat)
@@ -383,7 +407,7 @@ class Decoder(RuntimeStateMixin, nn.Module):
             # x_out = x_mid + c_proj(u)
             du = lin_bwd(pre + "mlp.c_proj.", dx, sv["u"])
             du_pre = new(B, 4 * D)
-            capi.quickgelu(sv["u_pre"], du_pre, du=du)
+            capi.quickgelu(sv["u_pre"], du_pre, du=du, drop=self._drop(drop_rng, 1 + i))
             dh2 = lin_bwd(pre + "mlp.c_fc.", du_pre, sv["h2"])
             dgam, dbet = new(D), new(D)
             capi.layernorm_bwd(sv["x_mid"], g(pre + "ln_2.weight"), dh2, dx, dgam, dbet, xhat, accumulate_dx=True)
@@ -405,7 +429,9 @@ class Decoder(RuntimeStateMixin, nn.Module):
             dgam, dbet = new(D), new(D)
             capi.layernorm_bwd(sv["x_in"], g(pre + "ln_1.weight"), dh1, dx, dgam, dbet, xhat, accumulate_dx=True)
             grads[pre + "ln_1.weight"], grads[pre + "ln_1.bias"] = dgam, dbet
-        # x_0 = ln_pre(class_embedding) for every clip
+        # x_0 = drop_pre(ln_pre(class_embedding)) for every clip
+        if self._drop(drop_rng, 0) is not None:
+            capi.dropout(dx, dx, self._drop(drop_rng, 0))
         dcls_rows = new(B, D)
         dgam, dbet = new(D), new(D)
         capi.layernorm_bwd(saved["x0"], g("ln_pre.weight"), dx, dcls_rows, dgam, dbet, xhat)
@@ -419,28 +445,32 @@ class Decoder(RuntimeStateMixin, nn.Module):
 
 
     # ---- HIP-graph replay of the training-step kernel sequences --------------------------------
-    def _graph_key(self, k_all, v_all, mask, dims, params):
+    def _graph_key(self, k_all, v_all, mask, dims, params, dropping):
         return (k_all.data_ptr(), v_all.data_ptr(), str(k_all.dtype), tuple(k_all.shape), dims, tuple(mask.shape),
-                tuple(p.data_ptr() for p in params), self.attn_modes, self.global_prediction)
+                tuple(p.data_ptr() for p in params), self.attn_modes, self.global_prediction, dropping, self.dropout_p)
 
-    def _graph_forward(self, w, k_all, v_all, mask, dims, params):
+    def _graph_forward(self, w, k_all, v_all, mask, dims, params, drop_rng=None):
         B, T, P = dims
-        key = self._graph_key(k_all, v_all, mask, dims, params)
+        key = self._graph_key(k_all, v_all, mask, dims, params, drop_rng is not None)
         graphs = _GRAPHS.setdefault(self, {})
         ent = graphs.get(key)
         if ent is None:
             if len(graphs) >= 4:  # addresses keep changing: graphs cannot help, stay eager
                 return None
-            ent = dict(mask=mask.clone(), bwd={})
-            self._forward_kernels(w, k_all, v_all, ent["mask"], B, T, P, save=True)  # eager once: lazy initialisations
+            # the dropout state is read from device memory by the kernels: the graph owns a static copy that is
+            # refreshed before every replay, so each step draws new masks and its backward regenerates them
+            ent = dict(mask=mask.clone(), bwd={}, rng=None if drop_rng is None else drop_rng.clone())
+            self._forward_kernels(w, k_all, v_all, ent["mask"], B, T, P, save=True, drop_rng=ent["rng"])  # eager once: lazy initialisations
             self._wt_cache.clear()  # the weight transposes must be nodes of the graph (weights change every step)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                raws, feat, outs, saved = self._forward_kernels(w, k_all, v_all, ent["mask"], B, T, P, save=True)
+                raws, feat, outs, saved = self._forward_kernels(w, k_all, v_all, ent["mask"], B, T, P, save=True, drop_rng=ent["rng"])
             ent.update(fwd=g, raws=raws, feat=feat, outs=outs, saved=saved)
             graphs[key] = ent
         ent["mask"].copy_(mask)
+        if drop_rng is not None:
+            ent["rng"].copy_(drop_rng)
         ent["fwd"].replay()
         return ent
 
@@ -477,15 +507,15 @@ class _DecoderFn(torch.autograd.Function):
     Outputs: (video_feature, *raw_logits, *normalised_logits)."""
 
     @staticmethod
-    def forward(ctx, dec, k_all, v_all, mask, dims, names, *params):
+    def forward(ctx, dec, k_all, v_all, mask, dims, names, drop_rng, *params):
         B, T, P = dims
         w = {n: p.detach() for n, p in zip(names, params)}
-        ent = dec._graph_forward(w, k_all, v_all, mask, dims, params) if dec.use_graphs else None
+        ent = dec._graph_forward(w, k_all, v_all, mask, dims, params, drop_rng) if dec.use_graphs else None
         if ent is not None:  # replayed graph: outputs live in the graph's static buffers, hand out copies
             raws, outs = [t.clone() for t in ent["raws"]], [t.clone() for t in ent["outs"]]
             feat, saved = ent["feat"].clone(), ent["saved"]
         else:
-            raws, feat, outs, saved = dec._forward_kernels(w, k_all, v_all, mask, B, T, P, save=True)
+            raws, feat, outs, saved = dec._forward_kernels(w, k_all, v_all, mask, B, T, P, save=True, drop_rng=drop_rng)
         ctx.graph_entry = ent
         ctx.after_backward, dec._after_backward = dec._after_backward, None
         ctx.dec, ctx.w, ctx.saved, ctx.dims, ctx.names = dec, w, saved, dims, names
@@ -508,4 +538,4 @@ class _DecoderFn(torch.autograd.Function):
         out = [grads.get(nm) if rq else None for nm, rq in zip(ctx.names, ctx.req)]
         if ctx.after_backward is not None:
             ctx.after_backward()
-        return (None, grads.get("__dk"), grads.get("__dv"), None, None, None, *out)
+        return (None, grads.get("__dk"), grads.get("__dv"), None, None, None, None, *out)

@@ -173,7 +173,8 @@ class ClipTransform:
 
 
 class Detector(RuntimeStateMixin, nn.Module):
-    _RUNTIME_STATE = {"_kv_static": None, "_enc_stream": None, "_pipe_events": [[], []], "_pipe_step": 0, "_pos_snap": None}
+    _RUNTIME_STATE = {"_kv_static": None, "_enc_stream": None, "_pipe_events": [[], []], "_pipe_step": 0, "_pos_snap": None,
+                      "_drop_master": None}
 
     def invalidate_caches(self):
         """Drop every device-side copy derived from the parameters (bf16 encoder weights, transposed decoder
@@ -242,6 +243,11 @@ class Detector(RuntimeStateMixin, nn.Module):
         self._pipe_events = [[], []]
         self._pipe_step = 0
         self._pos_snap = None
+        # train-mode dropout (reference models.py:163, :294, :304, :804-912; every configs/deepfake/*.yaml sets 0.5):
+        # counter-based masks from a device-resident {seed, step}; see `seed_dropout`
+        self.dropout_p = float(config.dropout) if "dropout" in config else 0.0
+        self._drop_seed = None
+        self._drop_master = None
         # trainable extras (reference models.py:488-496)
         if "temporal" in self.train_mode and self.train_mode.temporal == "ranking":
             self.ranking_transform_param = nn.Parameter((self.encoder.width ** -0.5) * torch.randn(self.encoder.width, 1),
@@ -259,6 +265,26 @@ class Detector(RuntimeStateMixin, nn.Module):
             if self.adapter is not None and self.adapter.struct.endswith("nln"):
                 raise NotImplementedError("patch_mask with the nln adapter: its LayerNorm is sized for all patches "
                                           "(the reference fails on this combination too)")
+
+    def seed_dropout(self, seed):
+        """Fix the dropout stream: the same seed (and the same number of training forwards since) gives the
+        same masks.  Unseeded, the stream starts from `torch.initial_seed()` (so `torch.manual_seed` before the
+        first training step makes a run repeatable); the process rank is folded in so ranks draw different masks."""
+        self._drop_seed = int(seed)
+        self._drop_master = None
+
+    def _next_drop_rng(self, device):
+        """This forward's dropout state (device int64 {seed, step}) — or None outside train() / with p == 0 — and
+        advance the step counter.  The decoder and the adapter of one forward share it (distinct sites)."""
+        if not self.training or self.dropout_p <= 0:
+            return None
+        if self._drop_master is None or self._drop_master.device != device:
+            from . import dist as ddist
+            seed = (self._drop_seed if self._drop_seed is not None else torch.initial_seed()) + 0x9E3779B97F4A7C15 * ddist.rank()
+            self._drop_master = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+        snap = self._drop_master.clone()
+        self._drop_master[1] += 1
+        return snap
 
     def _encode(self, x, t, pos, keep):
         """Encoder pass over the clips -> ((k, v) export, pipeline context or None).
@@ -333,6 +359,7 @@ class Detector(RuntimeStateMixin, nn.Module):
         pos = self.decoder.temporal_pos()
         self.decoder.use_graphs = False
         pipe = None
+        drop_rng = self._next_drop_rng(x.device)
         masked = train and "patch_mask" in self.train_mode
         if self.adapter is None and not masked:
             self.decoder.use_graphs = bool(self.static_graphs and train)
@@ -353,7 +380,7 @@ class Detector(RuntimeStateMixin, nn.Module):
             if self.adapter is not None:
                 self.adapter.patches = num_select
                 try:
-                    kv = self.adapter.run(kr, vr, t, pos)
+                    kv = self.adapter.run(kr, vr, t, pos, drop_rng)
                 finally:
                     self.adapter.patches = (self.encoder.input_resolution // self.encoder.patch_size) ** 2
             else:
@@ -368,10 +395,10 @@ class Detector(RuntimeStateMixin, nn.Module):
             kv, pipe = self._encode(x, t, None, keep=False)
             if pipe is not None:
                 self.adapter._after_backward = pipe[3].record  # its backward is the last reader of the raw export
-            kv = self.adapter.run(kv[0], kv[1], t, pos)
+            kv = self.adapter.run(kv[0], kv[1], t, pos, drop_rng)
         if pipe is not None:
             self.decoder._after_backward = pipe[2].record  # recorded on the backward's stream when it ends
-        _, video_features, task_logits = self.decoder.run(kv, m)
+        _, video_features, task_logits = self.decoder.run(kv, m, drop_rng)
         if pipe is not None:
             pipe[1].record(pipe[0])
         features = {}

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DFD_ABI_VERSION 9
+#define DFD_ABI_VERSION 10
 
 enum { DFD_F32 = 0, DFD_BF16 = 1 };
 
@@ -47,6 +47,18 @@ enum {
                               rows (patches) per frame                                            */
 };
 
+/* Train-mode dropout (models.py:163, :294, :304; adapter :804-912).  Masks are counter-based (Philox4x32-10 on
+ * (seed, step, site, element index)), generated inside the kernels and regenerated in the backward:
+ * rng_state is a DEVICE pointer to {seed, step} (uint64[2]; read at execution time, so a captured graph draws
+ * new masks when the host bumps step), site distinguishes the dropout layers of one step, p = drop probability
+ * (0 = identity, bit for bit).  Element e of a site is kept iff draw16(e) >= round(p*65536); kept values are
+ * scaled by 65536/(65536 - round(p*65536)).  Exact definition: dfd-clip_amd/csrc/dropout.hpp. */
+typedef struct dfd_dropout_t {
+  const uint64_t* rng_state;
+  uint32_t site;
+  float p;
+} dfd_dropout_t;
+
 typedef struct dfd_gemm_extra {
   /* PATCH_EMBED: encoder positional_embedding [tokens, N] f32.
      QKV_EXPORT : decoder temporal positional embedding viewed [frames_per_clip, N/3] f32, or NULL. */
@@ -59,6 +71,9 @@ typedef struct dfd_gemm_extra {
   const void* residual;    /* RESIDUAL_POS: residual source in c_dtype with C's leading dimension; NULL = C (in place) */
   int32_t qkv_first;       /* QKV_EXPORT: 0 = W / C columns are [q | k | v] (N = 3D); 1 = [k | v] only (N = 2D): the last
                               tapped layer needs no queries (nothing after its K/V export is read) */
+  const uint64_t* drop_rng; /* RESIDUAL_POS: dropout on acc before the residual add (the adapter's last nn.Dropout,   */
+  uint32_t drop_site;       /* models.py:807 etc.): C = residual + dropout(acc) + pos; element index = row*N + col;  */
+  float drop_p;             /* drop_rng NULL or drop_p 0 = none                                                      */
 } dfd_gemm_extra;
 
 const char* dfd_last_error(void);          /* host pointer, valid until the thread's next failing call */
@@ -172,7 +187,14 @@ int dfd_decoder_attn_modes_fwd(const float* q, const void* k, int kv_dtype, cons
  * logits = 5 z / (‖z‖₂ + 1e-10)  (models.py:342-343, :359, :551-553).  All f32. */
 int dfd_head_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* proj,
                  float* video_feature, float* raw_logits, float* logits, int B, int D, int out_dim, float eps,
-                 void* stream);
+                 const dfd_dropout_t* drop_post, void* stream);
+/* drop_post (may be NULL): the decoder's drop_post between ln_post and the projection (models.py:342):
+ * video_feature holds the DROPPED features, element index = clip*D + channel. */
+
+/* out = dropout(in) over n elements (element index = position), any mix of f32 / bf16; in place allowed.
+ * Also the backward of a dropped tensor (dx = mask·scale·dy with the same descriptor). */
+int dfd_dropout(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, const dfd_dropout_t* drop,
+                void* stream);
 
 /* CompInvAdapter middle stage (models.py:823-875): y = GELU_erf(LayerNorm(a)) on a [frames, patches, x]
  * tensor in `dtype`.  joint == 1 ("nln"): statistics over the whole (patches, x) slab of a frame, affine
@@ -227,8 +249,9 @@ int dfd_layernorm_bwd(const float* x, int64_t ldx, const float* gamma, const flo
                       int64_t lddx, float* dgamma, float* dbeta, float* xhat_ws, int rows, int cols, float eps,
                       int accumulate_dx, void* stream);
 
-/* QuickGELU on n elements: du == NULL: out = u·σ(1.702u); otherwise out = du · d/du[u·σ(1.702u)]. */
-int dfd_quickgelu(const float* u, const float* du, float* out, int64_t n, void* stream);
+/* QuickGELU on n elements: du == NULL: out = drop(u·σ(1.702u)); otherwise out = drop'(du) · d/du[u·σ(1.702u)].
+ * drop (may be NULL) = the decoder MLP's nn.Dropout after the activation (models.py:163), same mask both ways. */
+int dfd_quickgelu(const float* u, const float* du, float* out, int64_t n, const dfd_dropout_t* drop, void* stream);
 
 /* Backward of dfd_head_fwd after its LayerNorm: dz = ∂L/∂(raw logits) through 5z/(‖z‖+1e-10),
  * dfeat = dz·projᵀ (+ dfeat_ext if not NULL), dproj [D, out_dim] = featᵀ dz. */

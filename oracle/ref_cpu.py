@@ -81,8 +81,10 @@ def encoder_forward(w, x, heads, patch, prefix="encoder.", with_out=False, with_
     return kvs
 
 
-def adapter_forward(w, kvs, struct_type, prefix="adapter."):
-    """`CompInvAdapter.forward` in eval mode (reference `src/models.py:930-940`).  LayerNorm-then-GELU
+def adapter_forward(w, kvs, struct_type, prefix="adapter.", drop=None):
+    """`CompInvAdapter.forward` (reference `src/models.py:930-940`); `drop(site, tensor, div)` (train mode, see
+    oracle/dropout_mask.py) stands for the nn.Dropout layers: p/10 (p/5 for `768-x-768`, absent in `legacy-`)
+    before the second Linear and p after it, sites 1000 + 4(2i + {k: 0, v: 1}) + {0, 1}; None = eval mode.  LayerNorm-then-GELU
     structs (`:823-875`): Linear(D->x, no bias) -> LayerNorm (over (P, x) jointly for `nln`, over x
     for `ln`/`z0`) -> exact-erf GELU -> Linear(x->D, no bias), residual.  GELU-then-LayerNorm structs
     `768-x-768` (`:795-808`, output Linear at Sequential index 4) and `legacy-768-x-768` (`:809-821`,
@@ -103,7 +105,12 @@ def adapter_forward(w, kvs, struct_type, prefix="adapter."):
                 a = F.layer_norm(F.gelu(a), tuple(lw.shape), lw, lb, 1e-5)
             else:
                 a = F.gelu(F.layer_norm(a, tuple(lw.shape), lw, lb, 1e-5))
+            site = 1000 + 4 * (2 * i + (0 if name == "k" else 1))
+            if drop is not None and struct_type != "legacy-768-x-768":
+                a = drop(site, a, 5 if struct_type == "768-x-768" else 10)
             a = F.linear(a, w[f"{prefix}l{i}_{name}.{out_idx}.weight"])
+            if drop is not None:
+                a = drop(site + 1, a)
             new[name] = t + a.reshape(b, tt, p, h, d)
         out.append(new)
     return out
@@ -141,9 +148,10 @@ def decoder_attention(q_in, k, v, m, w, p, heads, num_frames, attn_mode=()):
 
 
 def decoder_forward(w, kvs, m, heads, out_dims, num_frames, layer_indices, prefix="decoder.",
-                    attn_mode=(), global_prediction=False):
-    """`Decoder.forward` in eval mode (reference `src/models.py:323-361`, block `:173-176`,
-    stack `:259-269`).  kvs: per selected layer k, v [B, T, P, heads, d]; m [B, T] bool.
+                    attn_mode=(), global_prediction=False, drop=None):
+    """`Decoder.forward` (reference `src/models.py:323-361`, block `:173-176`, stack `:259-269`); `drop(site,
+    tensor)` stands for drop_pre (site 0, `:337`), the MLP dropout of block i (site 1 + i, `:163`) and drop_post
+    (site 250 + head index, `:342`) in train mode; None = eval mode.  kvs: per selected layer k, v [B, T, P, heads, d]; m [B, T] bool.
     The temporal positional embedding [T, 1, heads, d] is added to BOTH k and v."""
     g = lambda k: w[prefix + k]
     patches = kvs[0]["k"].shape[2]
@@ -158,6 +166,8 @@ def decoder_forward(w, kvs, m, heads, out_dims, num_frames, layer_indices, prefi
     b = flat[0][0].shape[0]
     x = g("class_embedding").view(1, 1, -1).repeat(b, 1, 1)
     x = layer_norm(x, g("ln_pre.weight"), g("ln_pre.bias"))
+    if drop is not None:
+        x = drop(0, x)
     results = []
     for i, (k, v) in enumerate(flat):
         p = f"{prefix}transformer.resblocks.{i}."
@@ -165,6 +175,8 @@ def decoder_forward(w, kvs, m, heads, out_dims, num_frames, layer_indices, prefi
         x = x + decoder_attention(h, k, v, mk, w, p, heads, num_frames, attn_mode)
         h2 = layer_norm(x, w[p + "ln_2.weight"], w[p + "ln_2.bias"])
         u = quick_gelu(F.linear(h2, w[p + "mlp.c_fc.weight"], w[p + "mlp.c_fc.bias"]))
+        if drop is not None:
+            u = drop(1 + i, u)
         x = x + F.linear(u, w[p + "mlp.c_proj.weight"], w[p + "mlp.c_proj.bias"])
         results.append(x)
         aq = w.get(f"{prefix}transformer.augment_query_{i}")
@@ -174,6 +186,8 @@ def decoder_forward(w, kvs, m, heads, out_dims, num_frames, layer_indices, prefi
     if not global_prediction:
         x = x[:, -1]
     x = layer_norm(x, g("ln_post.weight"), g("ln_post.bias"))
+    if drop is not None:  # one nn.Dropout call in the reference; the product numbers the heads' slices separately
+        x = drop(250, x) if x.dim() == 2 else torch.stack([drop(250 + j, x[:, j]) for j in range(x.shape[1])], dim=1)
     video_feature = x.squeeze(1)
     logits = []
     for i, od in enumerate(out_dims):
@@ -198,7 +212,7 @@ def cross_entropy_per_sample(logits, y, weight=None, label_smoothing=0.0):
 
 
 def detector_predict(w, x, m, *, heads, patch, layer_indices, out_dims, num_frames,
-                     adapter_struct=None, attn_mode=(), global_prediction=False, return_kvs=False):
+                     adapter_struct=None, attn_mode=(), global_prediction=False, return_kvs=False, drop=None):
     """`Detector.predict` in eval mode (reference `src/models.py:498-566`): frozen encoder on
     the (B*T)-flattened frames, CLS row dropped, temporal axis restored, layers selected,
     optional adapter, decoder, logits rescaled to L2 norm 5."""
@@ -207,9 +221,9 @@ def detector_predict(w, x, m, *, heads, patch, layer_indices, out_dims, num_fram
         kvs = encoder_forward(w, x.flatten(0, 1), heads, patch)
         kvs = [{n: kvs[l][n][:, 1:].unflatten(0, (b, t)) for n in ("k", "v")} for l in layer_indices]
     if adapter_struct is not None:
-        kvs = adapter_forward(w, kvs, adapter_struct)
+        kvs = adapter_forward(w, kvs, adapter_struct, drop=drop)
     logits, feat = decoder_forward(w, kvs, m, heads, out_dims, num_frames, layer_indices,
-                                   attn_mode=attn_mode, global_prediction=global_prediction)
+                                   attn_mode=attn_mode, global_prediction=global_prediction, drop=drop)
     logits = [normalise_logits(z) for z in logits]
     if return_kvs:
         return logits, feat, kvs
