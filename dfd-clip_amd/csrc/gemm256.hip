@@ -45,6 +45,12 @@
 #ifndef LAB_SAME_TILE
 #define LAB_SAME_TILE 0
 #endif
+#ifndef LAB_NO_STORE
+#define LAB_NO_STORE 0
+#endif
+#ifndef LAB_NO_GELU
+#define LAB_NO_GELU 0
+#endif
 #ifndef DFD_GEMM256_TRY
 #define DFD_GEMM256_TRY dfd_gemm256_try
 #endif
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           f32x4 v = acc[i][j] + b4[j];
-          if constexpr (EPI == DFD_EPI_BIAS_QUICKGELU) {
+          if constexpr (EPI == DFD_EPI_BIAS_QUICKGELU && !LAB_NO_GELU) {
             // v * sigmoid(1.702 v) = v / (1 + 2^(-1.702*log2(e)*v)): the epilogue of this shape is VALU-bound
             // (two waves per SIMD, no MFMA left to hide behind), so the scale constants are folded into
             // one packed multiply and everything but v_exp_f32 / v_rcp_f32 stays in packed f32 ops
@@ -290,7 +296,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
         const int row = rr * 8 + (lane >> 3), c = lane & 7;
         const uint4 d = *reinterpret_cast<const uint4*>(ep + row * 128 + ((c ^ (row & 7)) << 4));
         const int64_t m = m0 + wr * 128 + row;
-        if (m < a.M) {
+        if (LAB_NO_STORE) {
+          if (d.x == 0x12345678u && d.y == 0x9abcdef0u) *reinterpret_cast<uint4*>(dst + m * a.ldc + nb + c * 8) = d;
+        } else if (m < a.M) {
           if (pass == 0) {
             *reinterpret_cast<uint4*>(dst + m * a.ldc + nb + c * 8) = d;
           } else {

@@ -11,6 +11,10 @@ v lab_same -DLAB_SAME_TILE=1
 v lab_same_noepi -DLAB_SAME_TILE=1 -DLAB_NO_EPILOGUE=1
 v lab_noepi -DLAB_NO_EPILOGUE=1
 v lab_noglds -DLAB_NO_GLDS=1
+v lab_nostore -DLAB_NO_STORE=1
+v lab_nogelu -DLAB_NO_GELU=1
+v lab_nostore_nogelu -DLAB_NO_STORE=1 -DLAB_NO_GELU=1
+v lab_same_nostore -DLAB_SAME_TILE=1 -DLAB_NO_STORE=1
 v lab_nods -DLAB_NO_DSREAD=1
 v lab_nobar -DLAB_NO_BARRIER=1
 v lab_noglds_nods -DLAB_NO_GLDS=1 -DLAB_NO_DSREAD=1

@@ -9,14 +9,14 @@
 void dfd_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fprintf(stderr, "\n"); }
 
 #define DECL(n) int n(const GemmArgs&, int, int, hipStream_t);
-DECL(lab_full) DECL(lab_same) DECL(lab_same_noepi) DECL(lab_noepi) DECL(lab_noglds) DECL(lab_nods) DECL(lab_nobar) DECL(lab_mfma_only) DECL(lab_noglds_nods)
+DECL(lab_full) DECL(lab_same) DECL(lab_same_noepi) DECL(lab_noepi) DECL(lab_noglds) DECL(lab_nods) DECL(lab_nobar) DECL(lab_mfma_only) DECL(lab_noglds_nods) DECL(lab_nostore) DECL(lab_nogelu) DECL(lab_nostore_nogelu) DECL(lab_same_nostore)
 
 int main() {
   const int64_t M = 480 * 197;
   struct Shape { const char* name; int N, K, epi, cdt; } shapes[] = {
-      {"c_fc", 3072, 768, DFD_EPI_BIAS_QUICKGELU, DFD_BF16}, {"c_proj", 768, 3072, DFD_EPI_BIAS_RESIDUAL, DFD_F32}};
+      {"c_fc", 3072, 768, DFD_EPI_BIAS_QUICKGELU, DFD_BF16}, {"qkv_plain", 2304, 768, DFD_EPI_BIAS, DFD_BF16}, {"c_proj/d", 768, 3072, DFD_EPI_BIAS, DFD_BF16}};
   struct Var { const char* name; int (*fn)(const GemmArgs&, int, int, hipStream_t); } vars[] = {
-      {"full", lab_full}, {"same_tile", lab_same}, {"same_tile_noepi", lab_same_noepi}, {"no_epilogue", lab_noepi}, {"no_glds", lab_noglds}, {"no_dsread", lab_nods},
+      {"full", lab_full}, {"no_store", lab_nostore}, {"no_gelu", lab_nogelu}, {"no_store_no_gelu", lab_nostore_nogelu}, {"same_tile_no_store", lab_same_nostore}, {"same_tile", lab_same}, {"same_tile_noepi", lab_same_noepi}, {"no_epilogue", lab_noepi}, {"no_glds", lab_noglds}, {"no_dsread", lab_nods},
       {"no_barrier", lab_nobar}, {"no_glds_no_dsread", lab_noglds_nods}, {"mfma_only", lab_mfma_only}};
   for (auto& sh : shapes) {
     void *A, *W, *C; float* bias;
