@@ -325,7 +325,12 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
   if (M == 0) return DFD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (ab_dtype == DFD_BF16) {
-    const int rc = dfd_gemm256_try(a, c_dtype, epilogue, st);
+    // a q|k|v projection without an export is a plain biased store
+    const int epi_p = epilogue == DFD_EPI_QKV_EXPORT && a.k_export == nullptr ? DFD_EPI_BIAS : epilogue;
+    int rc = epi_p == DFD_EPI_QKV_EXPORT ? 1 : dfd_gemm256p_try(a, c_dtype, epi_p, st);
+    if (rc == 0) g_last_path = 256;
+    if (rc <= 0) return rc;
+    rc = dfd_gemm256_try(a, c_dtype, epilogue, st);
     if (rc == 0) g_last_path = 256;
     if (rc <= 0) return rc;
   }

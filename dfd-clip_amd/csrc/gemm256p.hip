@@ -1,0 +1,417 @@
+// Persistent form of the tuned bf16 GEMM (gemm256.hip describes the 256x256 tile, the LDS ring, the XOR
+// swizzle and the four-phase K step; all of that is unchanged here).  What changes is what happens BETWEEN
+// tiles.  Ablations on MI355X (profiles/r02_gemm_ablation.txt) put the relaunching kernel's c_fc time at
+// 0.50 ms of which the MFMA loop with its loads is 0.29, the per-tile load prologue 0.05 and the epilogue 0.16
+// (0.07 of it the global stores: s_endpgm waits for them, so the next tile's workgroup cannot start).  So:
+//   * one workgroup per CU walks a list of tiles (grid = min(CUs, tiles));
+//   * the K loop is one flat sequence of 64-deep steps across tiles: the last two steps of a tile already
+//     request the first two steps of the next one, so a tile never starts with an empty ring;
+//   * operands come through buffer_load ... lds with ONE descriptor per matrix and 32-bit per-lane offsets
+//     (no 64-bit pointer sets to rebuild per tile); stores go through buffer_store with out-of-range offsets
+//     for masked rows, so every wave issues exactly S stores per tile;
+//   * vmcnt retires in issue order, so the epilogue's S stores are issued AFTER the next tile's first loads
+//     and the next tile's first wait is s_waitcnt vmcnt(S): the stores drain to HBM under the next tile's
+//     first K steps instead of in front of them;
+//   * epilogue staging lives in the 32 KB of LDS beside the 128 KB ring (4 KB per wave, 32 rows per pass).
+// Epilogues with a bf16 C: BIAS, BIAS_QUICKGELU, QKV_EXPORT (reference clip/model.py:186, :197, :208-212).
+#include <type_traits>
+
+#include "gemm_args.hpp"
+
+#ifndef LABP_NO_STORE
+#define LABP_NO_STORE 0
+#endif
+#ifndef LABP_NO_EPI
+#define LABP_NO_EPI 0
+#endif
+#ifndef LABP_STAGGER
+#define LABP_STAGGER 0
+#endif
+#ifndef LABP_STORE_AUX
+#define LABP_STORE_AUX 2  // nt: the output streams past L2 instead of evicting the operand panels (c_fc 0.46 -> 0.41 ms)
+#endif
+#ifndef DFD_GEMM256P_TRY
+#define DFD_GEMM256P_TRY dfd_gemm256p_try
+#endif
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int ROWB = TK * 2;            // 128 B per LDS row = one cache line
+constexpr int A_BYTES = TM * ROWB;      // 32 KB
+constexpr int SLOT = (TM + TN) * ROWB;  // 64 KB
+constexpr int RING = 2 * SLOT;          // 128 KB
+constexpr int STAGE = 4096;             // per wave: 32 rows x 128 B
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+struct Tile {
+  int m0, n0;
+};
+
+// tile order: column GROUPS of at most 6 tiles, inside a group row panel major / column minor (gemm256.hip)
+__device__ __forceinline__ Tile decode_tile(int idx, int tiles_m, int tiles_n) {
+  const int ngroups = (tiles_n + 5) / 6;
+  const int gcols = (tiles_n + ngroups - 1) / ngroups;
+  int grp = idx / (tiles_m * gcols);
+  grp = grp < ngroups - 1 ? grp : ngroups - 1;
+  const int rem = idx - grp * tiles_m * gcols;
+  const int cols_here = min(gcols, tiles_n - grp * gcols);
+  const int tm = rem / cols_here, tn = grp * gcols + (rem - tm * cols_here);
+  return Tile{tm * TM, tn * TN};
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[RING + 8 * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ntiles = tiles_m * tiles_n;
+
+  // XCD-aware, bijective position of this workgroup inside one round of the grid (blocks b and b+8 share an XCD):
+  // each XCD takes a contiguous run of the tile order every round
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = G >> 3, r8 = G & 7;
+  const int pos = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+
+  const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)(uint32_t)(a.M * a.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)(uint32_t)((int64_t)a.N * a.ldw * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdC = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)(uint32_t)(a.M * a.ldc * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias ? a.bias : reinterpret_cast<const float*>(a.W)), 0,
+                                                                        a.bias ? a.N * 4 : 0, 0x00020000);
+
+  // ---- LDS-DMA staging: wave w fills rows [32w, 32w+32) of A and of W in 8-row pieces (1 KiB each) ----------
+  // per-lane byte offsets of the four pieces into A / W.  They describe the tile whose steps are being REQUESTED:
+  // vA switches to the next tile two steps before the end of the current one, vW one step before.
+  uint32_t vA[4], vW[4];
+  const uint32_t lda2 = (uint32_t)(a.lda * 2), ldw2 = (uint32_t)(a.ldw * 2);
+  const uint32_t a_last = (uint32_t)(a.M - 1) * lda2;  // byte offset of the last valid row: rows beyond M re-read it
+  // Offsets are rebuilt from an opaque copy of the lane id in plain 32-bit arithmetic (tile part scalar, lane part
+  // two or three VALU ops): nothing lane-dependent has to stay live across the tile loop for them.
+  auto set_a = [&](const Tile& t) {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const uint32_t pr = (uint32_t)(l >> 3), pp = (uint32_t)(l & 7);
+    const uint32_t ch0 = (pp ^ (pr >> 1)) << 4;  // chunk swizzle ppos ^ ((row >> 1) & 7): rows 8p + prow -> (4 (p & 1)) ^ (prow >> 1)
+    const uint32_t row0 = ((uint32_t)t.m0 + (uint32_t)(wave * 32)) * lda2 + pr * lda2;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) vA[p] = min(row0 + (uint32_t)(p * 8) * lda2, a_last) + (ch0 ^ ((p & 1) << 6));
+  };
+  auto set_w = [&](const Tile& t) {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const uint32_t pr = (uint32_t)(l >> 3), pp = (uint32_t)(l & 7);
+    const uint32_t ch0 = (pp ^ (pr >> 1)) << 4;
+    const uint32_t row0 = ((uint32_t)t.n0 + (uint32_t)(wave * 32)) * ldw2 + pr * ldw2;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) vW[p] = row0 + (uint32_t)(p * 8) * ldw2 + (ch0 ^ ((p & 1) << 6));
+  };
+  auto issue_a = [&](int kt, int slot) {
+    unsigned char* d = smem + slot * SLOT + wave * 32 * ROWB;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(d + p * 8 * ROWB), 16, vA[p], kt * ROWB, 0, 0);
+  };
+  auto issue_w = [&](int kt, int slot) {
+    unsigned char* d = smem + slot * SLOT + A_BYTES + wave * 32 * ROWB;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdW, (lds_ptr_t)(d + p * 8 * ROWB), 16, vW[p], kt * ROWB, 0, 0);
+  };
+
+  // ---- fragment reads: lane (fr, fq) reads row fr of a 16-row block, chunk 4*ks + fq ----------------
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = (fr >> 1) & 7;
+  int offA[2], offW[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    offA[ks] = (wr * 128 + fr) * ROWB + (((4 * ks + fq) ^ sw) << 4);
+    offW[ks] = A_BYTES + (wc * 64 + fr) * ROWB + (((4 * ks + fq) ^ sw) << 4);
+  }
+  auto read_w = [&](bf16x8 (&w)[4], int slot, int ks) {
+    const unsigned char* sb = smem + slot * SLOT + offW[ks];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * ROWB);
+  };
+  auto read_a = [&](bf16x8 (&f)[4], int slot, int ks, int half) {
+    const unsigned char* sb = smem + slot * SLOT + offA[ks] + half * 64 * ROWB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * ROWB);
+  };
+
+  f32x4 acc[8][4];
+  auto phase = [&](const bf16x8 (&w)[4], const bf16x8 (&f)[4], int half, auto&& mid) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[4 * half][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], f[0], acc[4 * half][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    mid();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[4 * half + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], f[i], acc[4 * half + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (LABP_STAGGER) {
+    const int phase = (bid >> 3) & 7;
+    for (int i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(LABP_STAGGER);
+  }
+  const int nk = a.K / TK;  // >= 2
+  int idx = pos;            // < ntiles: the launcher keeps G <= ntiles
+  Tile cur = decode_tile(idx, tiles_m, tiles_n);
+  set_a(cur);
+  set_w(cur);
+  int par = 0;  // ring slot of the current tile's step 0
+  issue_a(0, 0);
+  issue_w(0, 0);
+  issue_a(1, 1);
+  issue_w(1, 1);
+  wait_vm<8>();  // step 0 landed, step 1 may be in flight
+  __builtin_amdgcn_s_barrier();
+  int s_prev = 0;  // stores of the previous epilogue still in flight when this tile's loop starts
+
+  bf16x8 wA[4], wB[4], lo[4], hi[4];
+  [[maybe_unused]] unsigned char* const ep = smem + RING + wave * STAGE;
+  const int D = EPI == DFD_EPI_QKV_EXPORT ? a.N / (3 - a.qkv_first) : 0;
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t srdK = srdC, srdV = srdC;
+  if constexpr (EPI == DFD_EPI_QKV_EXPORT) {
+    if (a.k_export != nullptr) {
+      const int64_t erows = (a.M / a.tokens) * (a.tokens - 1);
+      srdK = __builtin_amdgcn_make_buffer_rsrc(a.k_export, 0, (int)(uint32_t)(erows * D * 2), 0x00020000);
+      srdV = __builtin_amdgcn_make_buffer_rsrc(a.v_export, 0, (int)(uint32_t)(erows * D * 2), 0x00020000);
+    }
+  }
+
+  for (;;) {
+    const int nidx = idx + G;
+    const bool has_next = nidx < ntiles;
+    const Tile nxt = has_next ? decode_tile(nidx, tiles_m, tiles_n) : cur;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    read_w(wA, par, 0);
+    read_a(lo, par, 0, 0);
+    f32x4 b4[4];  // bias of this wave's 64 columns
+
+    // one 64-deep step; `last` (compile time) = the tile's final step, which requests only the next tile's operands,
+    // fetches the bias ahead of its wait (so that the epilogue never waits for a load) and reads no further fragments
+    auto kstep = [&](int kt, auto last_c) {
+      constexpr bool last = decltype(last_c)::value;
+      const int slot = (par + kt) & 1;
+      if (has_next) {  // the requests below move on to the next tile
+        if (kt == nk - 2) set_a(nxt);
+        if (kt == nk - 1) set_w(nxt);
+      }
+      // P0: k-half 0, rows 0-3 | prefetch rows 4-7 | request W of step kt+1 (a tile's step 1 is requested before its loop)
+      phase(wA, lo, 0, [&] {
+        read_a(hi, slot, 0, 1);
+        if (kt >= 1) {
+          if (!last) issue_w(kt + 1, slot ^ 1);
+          else if (has_next) issue_w(0, slot ^ 1);
+        }
+      });
+      // P1: k-half 0, rows 4-7 | prefetch k-half 1: W (second set) and rows 0-3
+      phase(wA, hi, 1, [&] {
+        read_w(wB, slot, 1);
+        read_a(lo, slot, 1, 0);
+      });
+      // P2: k-half 1, rows 0-3 | prefetch rows 4-7
+      phase(wB, lo, 0, [&] { read_a(hi, slot, 1, 1); });
+      if constexpr (last) {
+        int lb = lane;  // opaque: keeps the (tile-invariant) lane part of the address out of the loop-carried registers
+        asm volatile("" : "+v"(lb));
+        const uint32_t boff = a.bias ? (uint32_t)((cur.n0 + wc * 64 + (lb >> 4) * 4) * 4) : 0xffffffffu;  // no bias: out of range reads 0
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const v4i r = __builtin_amdgcn_raw_buffer_load_b128(srdB, boff, j * 64, 0);
+          b4[j] = __builtin_bit_cast(f32x4, r);
+        }
+      }
+      // my reads of this slot are done and step kt+1 has landed: after the barrier this slot is free and the other
+      // one readable.  In a tile's first step the youngest s_prev operations are the previous epilogue's stores:
+      // they stay in flight.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (kt == 0) {
+        if (s_prev == 0) wait_vm<0>();
+        else if (s_prev == 16) wait_vm<16>();
+        else wait_vm<32>();
+      } else {
+        wait_vm<0>();
+      }
+      if constexpr (last) {
+        // the bias has arrived with that wait; consuming it here keeps the compiler from placing its own (merged,
+        // hence vmcnt(0)) wait at the top of the epilogue, behind the next tile's first requests
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(b4[j]));
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // P3: k-half 1, rows 4-7 (registers only) | first fragments of step kt+1 | request A of step kt+2
+      phase(wB, hi, 1, [&] {
+        if constexpr (!last) {
+          read_w(wA, slot ^ 1, 0);
+          read_a(lo, slot ^ 1, 0, 0);
+        }
+        if (kt + 2 < nk) issue_a(kt + 2, slot);
+        else if (has_next) issue_a(kt + 2 - nk, slot);
+      });
+    };
+    for (int kt = 0; kt < nk - 1; ++kt) kstep(kt, std::false_type{});
+    kstep(nk - 1, std::true_type{});
+    if (has_next) issue_w(1, (par + nk - 1) & 1);  // ahead of the stores below: the next tile's first wait skips them
+
+    // ---- epilogue: 4 passes of 32 rows through this wave's 4 KB of staging; whole 128-byte row segments out ----
+    // Every address below is rebuilt from an opaque copy of the lane id: left to itself the compiler hoists two
+    // dozen tile-invariant address registers out of the tile loop and spills them (scratch traffic counts in vmcnt
+    // and would drain the stores this kernel exists to leave in flight).
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int er = le & 15, eq = le >> 4;          // accumulator fragment: row er of a 16-row block, columns 4*eq ..
+    const int drow = le >> 3, dc = le & 7;         // drain: row drow of an 8-row group, 16-byte chunk dc
+    const int nb = cur.n0 + wc * 64;
+    int which = 0;
+    if constexpr (EPI == DFD_EPI_QKV_EXPORT) which = cur.n0 / D + a.qkv_first;  // 0 = q, 1 = k, 2 = v
+    const bool exporting = EPI == DFD_EPI_QKV_EXPORT && which > 0 && a.k_export != nullptr;
+    const int passes = exporting ? 2 : 1;
+    unsigned char* const park = ep + er * 128 + ((eq ^ ((er & 7) << 1)) << 3);  // + ii*2048, ^ (j << 5)
+    const unsigned char* const dsrc = ep + drow * 128 + ((dc ^ drow) << 4);     // + rr*1024
+    const int rows_left = (int)min((int64_t)0x7fffffff, a.M - ((int64_t)cur.m0 + wr * 128 + drow));  // rows [.., M) of this lane's first
+    const uint32_t cbase = (uint32_t)((((int64_t)cur.m0 + wr * 128 + drow) * a.ldc + nb + dc * 8) * 2);
+    // exported copy first: its positional-embedding loads then wait only for loads, never for this tile's stores
+    if (LABP_NO_EPI) {
+      f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t += acc[i][j];
+      if (t[0] == 123.456f) static_cast<float*>(a.C)[0] = t[1] + t[2] + t[3] + b4[0][0];
+    } else
+    for (int pass = passes - 1; pass >= 0; --pass) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int i = 2 * q + ii;
+          f32x4 p4[4];
+          if (pass == 1) {  // exported copy = f32 value + temporal positional embedding, rounded once
+            const int64_t m = (int64_t)cur.m0 + wr * 128 + i * 16 + er;
+            const uint32_t frame = (uint32_t)(m < a.M ? m : a.M - 1) / (uint32_t)a.tokens;
+            const float* pr = a.pos ? a.pos + (int64_t)(frame % (uint32_t)a.frames_per_clip) * D + (nb - (which - a.qkv_first) * D) + eq * 4 : nullptr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p4[j] = pr ? *reinterpret_cast<const f32x4*>(pr + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f32x4 v = acc[i][j] + b4[j];
+            if constexpr (EPI == DFD_EPI_BIAS_QUICKGELU) {
+              float cgelu = DFD_QUICKGELU_SCALE;  // opaque + in an SGPR so that the multiply packs (gemm256.hip)
+              asm volatile("" : "+s"(cgelu));
+              const f32x4 t = v * cgelu;
+              f32x4 d;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_exp2f(t[e]);
+              d = d + 1.0f;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_rcpf(d[e]);
+              v = v * d;
+            }
+            if (pass == 1) v += p4[j];
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+            // row ii*16 + er, 8-byte unit (j*4 + eq) ^ ((row & 7) << 1)
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<unsigned char*>(reinterpret_cast<uintptr_t>(park + ii * 2048) ^ (uintptr_t)(j << 5))) = o;
+          }
+        }
+        // drain: 4 wave-stores of 8 rows x 128 B
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const v4i d = *reinterpret_cast<const v4i*>(dsrc + rr * 1024);
+          const int rloc = q * 32 + rr * 8;  // row of the store relative to this lane's first row
+          if (pass == 0) {
+            uint32_t off = rloc < rows_left ? cbase + (uint32_t)rloc * (uint32_t)(a.ldc * 2) : 0xffffffffu;  // out of range: dropped
+            if (LABP_NO_STORE) off = d.x == 0x12345678 ? off : 0xffffffffu;
+            __builtin_amdgcn_raw_buffer_store_b128(d, srdC, off, 0, LABP_STORE_AUX);
+          } else {
+            const int64_t m = (int64_t)cur.m0 + wr * 128 + drow + rloc;
+            const uint32_t mm = (uint32_t)(m < a.M ? m : 0);
+            const uint32_t frame = mm / (uint32_t)a.tokens;
+            const int tok = (int)(mm - frame * (uint32_t)a.tokens);
+            uint32_t off = 0xffffffffu;
+            if (m < a.M && tok > 0)
+              off = (uint32_t)((((int64_t)frame * (a.tokens - 1) + tok - 1) * D + (nb - (which - a.qkv_first) * D) + dc * 8) * 2);
+            __builtin_amdgcn_raw_buffer_store_b128(d, which == 2 ? srdV : srdK, off, 0, 0);
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    s_prev = 16 * passes;
+    par = (par + nk) & 1;
+    idx = nidx;
+    cur = nxt;
+  }
+}
+
+template <int EPI>
+int launch256p(const GemmArgs& a, hipStream_t st) {
+  const int tiles_n = a.N / TN;
+  const int tiles_m = (int)((a.M + TM - 1) / TM);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      dfd_set_error("dfd_gemm(persistent bf16): cannot query the device");
+      return DFD_ERR_LAUNCH;
+    }
+    n_cu = prop.multiProcessorCount;
+  }
+  const int64_t ntiles = (int64_t)tiles_m * tiles_n;
+  const int grid = (int)(ntiles < n_cu ? ntiles : n_cu);
+  hipLaunchKernelGGL((gemm256p_kernel<EPI>), dim3(grid), dim3(512), 0, st, a, tiles_m, tiles_n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    dfd_set_error("dfd_gemm(persistent bf16): launch failed: %s", hipGetErrorString(e));
+    return DFD_ERR_LAUNCH;
+  }
+  return DFD_OK;
+}
+
+}  // namespace
+
+// 0 = launched, <0 = error, 1 = shape / epilogue not served by this kernel
+int DFD_GEMM256P_TRY(const GemmArgs& a, int c_dtype, int epi, hipStream_t st) {
+  if (c_dtype != DFD_BF16) return 1;
+  if (a.N % TN != 0 || a.K % 64 != 0 || a.K < 128 || a.M < 1024) return 1;
+  if ((a.lda % 8) != 0 || (a.ldw % 8) != 0 || (a.ldc % 8) != 0) return 1;
+  if ((reinterpret_cast<uintptr_t>(a.C) & 15) != 0) return 1;
+  if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15) != 0) return 1;
+  // buffer descriptors carry 32-bit byte offsets
+  const int64_t lim = (int64_t)0xfffffff0;
+  if (a.M * a.lda * 2 > lim || (int64_t)a.N * a.ldw * 2 > lim || a.M * a.ldc * 2 > lim) return 1;
+  if ((int64_t)((a.M + TM - 1) / TM) * (a.N / TN) > 0x3fffffff) return 1;
+  switch (epi) {
+    case DFD_EPI_BIAS:
+      return launch256p<DFD_EPI_BIAS>(a, st);
+    case DFD_EPI_BIAS_QUICKGELU:
+      return launch256p<DFD_EPI_BIAS_QUICKGELU>(a, st);
+    case DFD_EPI_QKV_EXPORT:
+      if ((a.N / (3 - a.qkv_first)) % TN != 0) return 1;
+      if (a.pos && (reinterpret_cast<uintptr_t>(a.pos) & 15) != 0) return 1;
+      if (a.k_export && (a.M / a.tokens) * (a.tokens - 1) * (int64_t)(a.N / (3 - a.qkv_first)) * 2 > lim) return 1;
+      return launch256p<DFD_EPI_QKV_EXPORT>(a, st);
+    default:
+      return 1;
+  }
+}

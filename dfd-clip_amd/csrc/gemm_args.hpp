@@ -18,5 +18,6 @@ struct GemmArgs {
   DfdDrop drop;   // RESIDUAL_POS: dropout on the accumulator (element index row*N + col); thr16 == 0: none
 };
 
-// tuned bf16 kernel (gemm256.hip): 0 = launched, <0 = error, 1 = shape not eligible
-int dfd_gemm256_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st);
+// tuned bf16 kernels: 0 = launched, <0 = error, 1 = shape / epilogue not eligible
+int dfd_gemm256_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st);   // gemm256.hip: one workgroup per tile
+int dfd_gemm256p_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st);  // gemm256p.hip: persistent, bf16 C

@@ -9,15 +9,14 @@
 void dfd_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fprintf(stderr, "\n"); }
 
 #define DECL(n) int n(const GemmArgs&, int, int, hipStream_t);
-DECL(lab_full) DECL(lab_same) DECL(lab_same_noepi) DECL(lab_noepi) DECL(lab_noglds) DECL(lab_nods) DECL(lab_nobar) DECL(lab_mfma_only) DECL(lab_noglds_nods) DECL(lab_nostore) DECL(lab_nogelu) DECL(lab_nostore_nogelu) DECL(lab_same_nostore)
+DECL(lab_full) DECL(lab_same) DECL(lab_same_noepi) DECL(lab_noepi) DECL(lab_noglds) DECL(lab_nods) DECL(lab_nobar) DECL(lab_mfma_only) DECL(lab_noglds_nods) DECL(dfd_gemm256p_try) DECL(labp_nostore) DECL(labp_noepi) DECL(labp_a1) DECL(labp_a3) DECL(labp_a16) DECL(labp_a18) DECL(labp_nt) DECL(lab_nt) DECL(lab_nostore) DECL(lab_nogelu) DECL(lab_nostore_nogelu) DECL(lab_same_nostore)
 
 int main() {
   const int64_t M = 480 * 197;
   struct Shape { const char* name; int N, K, epi, cdt; } shapes[] = {
-      {"c_fc", 3072, 768, DFD_EPI_BIAS_QUICKGELU, DFD_BF16}, {"qkv_plain", 2304, 768, DFD_EPI_BIAS, DFD_BF16}, {"c_proj/d", 768, 3072, DFD_EPI_BIAS, DFD_BF16}};
+      {"c_fc", 3072, 768, DFD_EPI_BIAS_QUICKGELU, DFD_BF16}, {"qkv_plain", 2304, 768, DFD_EPI_BIAS, DFD_BF16}, {"c_proj/d", 768, 3072, DFD_EPI_BIAS, DFD_BF16}, {"out_proj/d", 768, 768, DFD_EPI_BIAS, DFD_BF16}};
   struct Var { const char* name; int (*fn)(const GemmArgs&, int, int, hipStream_t); } vars[] = {
-      {"full", lab_full}, {"no_store", lab_nostore}, {"no_gelu", lab_nogelu}, {"no_store_no_gelu", lab_nostore_nogelu}, {"same_tile_no_store", lab_same_nostore}, {"same_tile", lab_same}, {"same_tile_noepi", lab_same_noepi}, {"no_epilogue", lab_noepi}, {"no_glds", lab_noglds}, {"no_dsread", lab_nods},
-      {"no_barrier", lab_nobar}, {"no_glds_no_dsread", lab_noglds_nods}, {"mfma_only", lab_mfma_only}};
+      {"full", lab_full}, {"persistent", dfd_gemm256p_try}, {"full", lab_full}, {"persistent", dfd_gemm256p_try}, {"full_nt", lab_nt}, {"P_nt", labp_nt}, {"P_aux1_sc0", labp_a1}, {"P_aux3_sc0nt", labp_a3}, {"P_aux16_sc1", labp_a16}, {"P_aux18_sc1nt", labp_a18}, {"full_nt", lab_nt}, {"P_nt", labp_nt}, {"persistent", dfd_gemm256p_try}, {"P_no_store", labp_nostore}, {"P_no_epilogue", labp_noepi}, {"no_store", lab_nostore}, {"no_epilogue", lab_noepi}, {"mfma_only", lab_mfma_only}};
   for (auto& sh : shapes) {
     void *A, *W, *C; float* bias;
     hipMalloc(&A, M * sh.K * 2); hipMalloc(&W, (size_t)sh.N * sh.K * 2); hipMalloc(&C, M * sh.N * 4); hipMalloc(&bias, sh.N * 4);
@@ -29,6 +28,16 @@ int main() {
     GemmArgs a{}; a.A = A; a.W = W; a.C = C; a.bias = bias; a.lda = sh.K; a.ldw = sh.K; a.ldc = sh.N; a.M = M; a.N = sh.N; a.K = sh.K;
     for (int i = 0; i < 20; ++i) lab_full(a, sh.cdt, sh.epi, 0);  // warm-up: clocks, caches, lazy code load (the first
     hipDeviceSynchronize();                                       // variant measured used to read ~10 % low without it)
+    {  // the persistent kernel must reproduce the relaunching kernel bit for bit (same MFMA order, same epilogue arithmetic)
+      std::vector<unsigned short> c0((size_t)M * sh.N), c1((size_t)M * sh.N);
+      hipMemset(C, 0xff, M * sh.N * 2); lab_full(a, sh.cdt, sh.epi, 0); hipDeviceSynchronize();
+      hipMemcpy(c0.data(), C, M * sh.N * 2, hipMemcpyDeviceToHost);
+      hipMemset(C, 0xff, M * sh.N * 2); int rc = dfd_gemm256p_try(a, sh.cdt, sh.epi, 0); hipError_t e = hipDeviceSynchronize();
+      hipMemcpy(c1.data(), C, M * sh.N * 2, hipMemcpyDeviceToHost);
+      size_t bad = 0; for (size_t i = 0; i < c0.size(); ++i) bad += c0[i] != c1[i];
+      printf("%-7s persistent vs full: rc=%d sync=%s mismatching elements = %zu of %zu\n", sh.name, rc, hipGetErrorString(e), bad, c0.size());
+      fflush(stdout);
+    }
     for (auto& v : vars) {
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
       for (int i = 0; i < 3; ++i) v.fn(a, sh.cdt, sh.epi, 0);
