@@ -59,6 +59,9 @@ def parse():
                     help="f32: frames already transformed (the headline's input); u8: raw uint8 frames through the ingest kernel")
     ap.add_argument("--ingest-size", type=int, nargs=2, default=None, metavar=("H", "W"),
                     help="with --ingest u8: source frame size (default = the model's resolution, i.e. no resize)")
+    ap.add_argument("--spare-cus", type=int, default=-1, help="CUs the encoder GEMMs leave to the decoder stream in pipelined training (-1 = package default)")
+    ap.add_argument("--gemm-stream-out", default=None,
+                    help="comma list of encoder GEMM outputs stored non-temporally (qkv,out,fc,proj; 'none'); default = package default")
     ap.add_argument("--adapter", default="none", choices=["none", "nln", "z0", "ln"],
                     help="CompInvAdapter 768-x-768-<struct>, x = 256 (every configs/deepfake/*.yaml enables one); default none = headline")
     return ap.parse_args()
@@ -87,6 +90,11 @@ def build_model(args, device):
         det.encoder.frame_chunk = args.frame_chunk
     if args.streams >= 0:
         det.encoder.streams = args.streams
+    if args.spare_cus >= 0:
+        det.pipeline_spare_cus = args.spare_cus
+    if args.gemm_stream_out is not None:
+        on = set(args.gemm_stream_out.split(",")) - {"none", ""}
+        det.encoder.stream_out = {k: k in on for k in det.encoder.stream_out}
     return det, cfg, sd, layers
 
 

@@ -316,6 +316,8 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
     a.residual = epilogue == DFD_EPI_RESIDUAL_POS ? extra->residual : nullptr;
     a.tokens = extra->tokens; a.frames_per_clip = extra->frames_per_clip > 0 ? extra->frames_per_clip : 1;
     a.qkv_first = epilogue == DFD_EPI_QKV_EXPORT ? extra->qkv_first : 0;
+    a.stream_out = (extra->flags & DFD_GEMM_STREAM_OUT) ? 1 : 0;
+    a.spare_cus = (int)((extra->flags >> DFD_GEMM_SPARE_CUS_SHIFT) & 0xff);
     if (epilogue == DFD_EPI_RESIDUAL_POS && extra->drop_rng && extra->drop_p > 0.f) {
       DFD_REQUIRE(extra->drop_p < 1.f, "dfd_gemm: drop_p=%f", (double)extra->drop_p);
       const dfd_dropout_t dd{extra->drop_rng, extra->drop_site, extra->drop_p};
@@ -327,7 +329,7 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
   if (ab_dtype == DFD_BF16) {
     // a q|k|v projection without an export is a plain biased store
     const int epi_p = epilogue == DFD_EPI_QKV_EXPORT && a.k_export == nullptr ? DFD_EPI_BIAS : epilogue;
-    int rc = epi_p == DFD_EPI_QKV_EXPORT ? 1 : dfd_gemm256p_try(a, c_dtype, epi_p, st);
+    int rc = dfd_gemm256p_try(a, c_dtype, epi_p, st);
     if (rc == 0) g_last_path = 256;
     if (rc <= 0) return rc;
     rc = dfd_gemm256_try(a, c_dtype, epilogue, st);

@@ -299,17 +299,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
         if (LAB_NO_STORE) {
           if (d.x == 0x12345678u && d.y == 0x9abcdef0u) *reinterpret_cast<uint4*>(dst + m * a.ldc + nb + c * 8) = d;
         } else if (m < a.M) {
-          // non-temporal stores: the output streams past L2 instead of evicting the operand panels the other
+          // stream_out: non-temporal stores, the output goes past L2 instead of evicting the operand panels the other
           // workgroups of the XCD are still reading (c_fc 0.486 -> 0.446 ms, QKV 0.361 -> 0.326 ms on MI355X)
           typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
           const u32x4 dn{d.x, d.y, d.z, d.w};
           if (pass == 0) {
-            __builtin_nontemporal_store(dn, reinterpret_cast<u32x4*>(dst + m * a.ldc + nb + c * 8));
+            u32x4* cp = reinterpret_cast<u32x4*>(dst + m * a.ldc + nb + c * 8);
+            if (a.stream_out) __builtin_nontemporal_store(dn, cp);
+            else *cp = dn;
           } else {
             const uint32_t frame = (uint32_t)m / (uint32_t)a.tokens;
             const int tok = (int)((uint32_t)m - frame * (uint32_t)a.tokens);
-            if (tok > 0)
-              __builtin_nontemporal_store(dn, reinterpret_cast<u32x4*>(dst + ((int64_t)frame * (a.tokens - 1) + tok - 1) * D + (nb - (which - a.qkv_first) * D) + c * 8));
+            if (tok > 0) {
+              u32x4* ep_ = reinterpret_cast<u32x4*>(dst + ((int64_t)frame * (a.tokens - 1) + tok - 1) * D + (nb - (which - a.qkv_first) * D) + c * 8);
+              if (a.stream_out) __builtin_nontemporal_store(dn, ep_);
+              else *ep_ = dn;
+            }
           }
         }
       }

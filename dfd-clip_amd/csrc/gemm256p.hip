@@ -18,6 +18,9 @@
 
 #include "gemm_args.hpp"
 
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef v4i_t v4i;
+
 #ifndef LABP_NO_STORE
 #define LABP_NO_STORE 0
 #endif
@@ -28,13 +31,25 @@
 #define LABP_STAGGER 0
 #endif
 #ifndef LABP_STORE_AUX
-#define LABP_STORE_AUX 2  // nt: the output streams past L2 instead of evicting the operand panels (c_fc 0.46 -> 0.41 ms)
+#define LABP_STORE_AUX -1  // -1: GemmArgs.stream_out decides (product); >= 0: fixed cache-policy bits (lab)
 #endif
 #ifndef DFD_GEMM256P_TRY
 #define DFD_GEMM256P_TRY dfd_gemm256p_try
 #endif
 
 namespace {
+
+// Output stores: non-temporal (aux bit 1) when the caller marks the output as streaming: it then goes past L2
+// instead of evicting the operand panels the XCD's other workgroups are reading (c_fc 0.46 -> 0.41 ms).
+__device__ __forceinline__ void store_out(v4i_t d, __amdgpu_buffer_rsrc_t srd, uint32_t off, int stream_out) {
+  if (LABP_STORE_AUX >= 0) {
+    __builtin_amdgcn_raw_buffer_store_b128(d, srd, off, 0, LABP_STORE_AUX < 0 ? 0 : LABP_STORE_AUX);
+  } else if (stream_out) {
+    __builtin_amdgcn_raw_buffer_store_b128(d, srd, off, 0, 2);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b128(d, srd, off, 0, 0);
+  }
+}
 
 constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int ROWB = TK * 2;            // 128 B per LDS row = one cache line
@@ -43,7 +58,6 @@ constexpr int SLOT = (TM + TN) * ROWB;  // 64 KB
 constexpr int RING = 2 * SLOT;          // 128 KB
 constexpr int STAGE = 4096;             // per wave: 32 rows x 128 B
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef int v4i __attribute__((ext_vector_type(4)));
 
 struct Tile {
   int m0, n0;
@@ -182,9 +196,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
   bf16x8 wA[4], wB[4], lo[4], hi[4];
   [[maybe_unused]] unsigned char* const ep = smem + RING + wave * STAGE;
   const int D = EPI == DFD_EPI_QKV_EXPORT ? a.N / (3 - a.qkv_first) : 0;
-  [[maybe_unused]] __amdgpu_buffer_rsrc_t srdK = srdC, srdV = srdC;
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t srdK = srdC, srdV = srdC, srdP = srdC;
   if constexpr (EPI == DFD_EPI_QKV_EXPORT) {
     if (a.k_export != nullptr) {
+      srdP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pos ? a.pos : reinterpret_cast<const float*>(a.W)), 0,
+                                               a.pos ? a.frames_per_clip * D * 4 : 0, 0x00020000);
       const int64_t erows = (a.M / a.tokens) * (a.tokens - 1);
       srdK = __builtin_amdgcn_make_buffer_rsrc(a.k_export, 0, (int)(uint32_t)(erows * D * 2), 0x00020000);
       srdV = __builtin_amdgcn_make_buffer_rsrc(a.v_export, 0, (int)(uint32_t)(erows * D * 2), 0x00020000);
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
     kstep(nk - 1, std::true_type{});
     if (has_next) issue_w(1, (par + nk - 1) & 1);  // ahead of the stores below: the next tile's first wait skips them
 
-    // ---- epilogue: 4 passes of 32 rows through this wave's 4 KB of staging; whole 128-byte row segments out ----
+    // ---- epilogue ------------------------------------------------------------------------------------------------
     // Every address below is rebuilt from an opaque copy of the lane id: left to itself the compiler hoists two
     // dozen tile-invariant address registers out of the tile loop and spills them (scratch traffic counts in vmcnt
     // and would drain the stores this kernel exists to leave in flight).
@@ -279,40 +295,83 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
     const int er = le & 15, eq = le >> 4;          // accumulator fragment: row er of a 16-row block, columns 4*eq ..
     const int drow = le >> 3, dc = le & 7;         // drain: row drow of an 8-row group, 16-byte chunk dc
     const int nb = cur.n0 + wc * 64;
+    const int64_t mrow0 = (int64_t)cur.m0 + wr * 128 + drow;  // first row this lane stores
+    const int rows_left = (int)min((int64_t)0x7fffffff, a.M - mrow0);
     int which = 0;
     if constexpr (EPI == DFD_EPI_QKV_EXPORT) which = cur.n0 / D + a.qkv_first;  // 0 = q, 1 = k, 2 = v
     const bool exporting = EPI == DFD_EPI_QKV_EXPORT && which > 0 && a.k_export != nullptr;
-    const int passes = exporting ? 2 : 1;
-    unsigned char* const park = ep + er * 128 + ((eq ^ ((er & 7) << 1)) << 3);  // + ii*2048, ^ (j << 5)
-    const unsigned char* const dsrc = ep + drow * 128 + ((dc ^ drow) << 4);     // + rr*1024
-    const int rows_left = (int)min((int64_t)0x7fffffff, a.M - ((int64_t)cur.m0 + wr * 128 + drow));  // rows [.., M) of this lane's first
-    const uint32_t cbase = (uint32_t)((((int64_t)cur.m0 + wr * 128 + drow) * a.ldc + nb + dc * 8) * 2);
-    // exported copy first: its positional-embedding loads then wait only for loads, never for this tile's stores
+    int stores = 16;
     if (LABP_NO_EPI) {
       f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) t += acc[i][j];
-      if (t[0] == 123.456f) static_cast<float*>(a.C)[0] = t[1] + t[2] + t[3] + b4[0][0];
-    } else
-    for (int pass = passes - 1; pass >= 0; --pass) {
+      if (t[0] == 123.456f) static_cast<float*>(a.C)[0] = t[1] + t[2] + t[3] + b4[0][0] + b4[1][0] + b4[2][0] + b4[3][0];
+    } else {
+      // bias once, in place: both copies of an exported tile read the same registers
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += b4[j];
+      if constexpr (EPI == DFD_EPI_QKV_EXPORT) {
+        if (exporting) {
+          // Exported copy of a K / V tile FIRST (its positional-embedding loads then wait only for loads, never for
+          // this tile's stores): bf16(acc + bias + pos[frame % T]) -> row frame*(tokens-1) + token-1 of the export,
+          // the CLS row dropped.  Eight sub-passes of 16 rows parked as f32 (4 KB); the drain adds the embedding
+          // (two 16-byte loads per store, requested at the top of the sub-pass) and rounds once.
+          stores = 32;
+          const int ecol = nb - (which - a.qkv_first) * D + dc * 8;  // first of this lane's 8 export columns
+          unsigned char* const parkf = ep + er * 256;                 // unit (j*4 + eq) ^ er of a 256-byte row
+          const __amdgpu_buffer_rsrc_t srdE = which == 2 ? srdV : srdK;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_barrier(0);  // keep each sub-pass's embedding loads inside it (16 registers, not 128)
+            uint32_t eoff[2];
+            f32x4 pe[2][2];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+              const int rloc = i * 16 + rr * 8;
+              const uint32_t m = (uint32_t)min(mrow0 + rloc, a.M - 1);
+              const uint32_t frame = a.div_tokens.div(m);
+              const uint32_t tok = m - frame * (uint32_t)a.tokens;
+              const uint32_t t = frame - a.div_frames.div(frame) * (uint32_t)a.frames_per_clip;
+              eoff[rr] = (rloc < rows_left && tok > 0) ? ((frame * (uint32_t)(a.tokens - 1) + tok - 1) * (uint32_t)D + ecol) * 2 : 0xffffffffu;
+              const uint32_t poff = a.pos ? (t * (uint32_t)D + ecol) * 4 : 0xffffffffu;  // no embedding: out of range reads 0
+              pe[rr][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdP, poff, 0, 0));
+              pe[rr][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdP, poff, 16, 0));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              *reinterpret_cast<f32x4*>(parkf + (((j * 4 + eq) ^ er) << 4)) = acc[i][j];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+              const int row = rr * 8 + drow;
+              const f32x4 x0 = *reinterpret_cast<const f32x4*>(ep + row * 256 + (((2 * dc) ^ row) << 4)) + pe[rr][0];
+              const f32x4 x1 = *reinterpret_cast<const f32x4*>(ep + row * 256 + (((2 * dc + 1) ^ row) << 4)) + pe[rr][1];
+              bf16x8 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                o[e] = (bf16_t)x0[e];
+                o[4 + e] = (bf16_t)x1[e];
+              }
+              store_out(__builtin_bit_cast(v4i, o), srdE, eoff[rr], a.stream_out);
+            }
+          }
+        }
+      }
+      // C itself: 4 passes of 32 rows parked as bf16 (4 KB); 16 wave-stores of 8 rows x 128 B
+      unsigned char* const park = ep + er * 128 + ((eq ^ ((er & 7) << 1)) << 3);  // + ii*2048, ^ (j << 5)
+      const unsigned char* const dsrc = ep + drow * 128 + ((dc ^ drow) << 4);     // + rr*1024
+      const uint32_t cbase = (uint32_t)((mrow0 * a.ldc + nb + dc * 8) * 2);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
           const int i = 2 * q + ii;
-          f32x4 p4[4];
-          if (pass == 1) {  // exported copy = f32 value + temporal positional embedding, rounded once
-            const int64_t m = (int64_t)cur.m0 + wr * 128 + i * 16 + er;
-            const uint32_t frame = (uint32_t)(m < a.M ? m : a.M - 1) / (uint32_t)a.tokens;
-            const float* pr = a.pos ? a.pos + (int64_t)(frame % (uint32_t)a.frames_per_clip) * D + (nb - (which - a.qkv_first) * D) + eq * 4 : nullptr;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) p4[j] = pr ? *reinterpret_cast<const f32x4*>(pr + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-          }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            f32x4 v = acc[i][j] + b4[j];
+            f32x4 v = acc[i][j];
             if constexpr (EPI == DFD_EPI_BIAS_QUICKGELU) {
               float cgelu = DFD_QUICKGELU_SCALE;  // opaque + in an SGPR so that the multiply packs (gemm256.hip)
               asm volatile("" : "+s"(cgelu));
@@ -325,7 +384,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
               for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_rcpf(d[e]);
               v = v * d;
             }
-            if (pass == 1) v += p4[j];
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
@@ -333,30 +391,18 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
             *reinterpret_cast<bf16x4*>(reinterpret_cast<unsigned char*>(reinterpret_cast<uintptr_t>(park + ii * 2048) ^ (uintptr_t)(j << 5))) = o;
           }
         }
-        // drain: 4 wave-stores of 8 rows x 128 B
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const v4i d = *reinterpret_cast<const v4i*>(dsrc + rr * 1024);
           const int rloc = q * 32 + rr * 8;  // row of the store relative to this lane's first row
-          if (pass == 0) {
-            uint32_t off = rloc < rows_left ? cbase + (uint32_t)rloc * (uint32_t)(a.ldc * 2) : 0xffffffffu;  // out of range: dropped
-            if (LABP_NO_STORE) off = d.x == 0x12345678 ? off : 0xffffffffu;
-            __builtin_amdgcn_raw_buffer_store_b128(d, srdC, off, 0, LABP_STORE_AUX);
-          } else {
-            const int64_t m = (int64_t)cur.m0 + wr * 128 + drow + rloc;
-            const uint32_t mm = (uint32_t)(m < a.M ? m : 0);
-            const uint32_t frame = mm / (uint32_t)a.tokens;
-            const int tok = (int)(mm - frame * (uint32_t)a.tokens);
-            uint32_t off = 0xffffffffu;
-            if (m < a.M && tok > 0)
-              off = (uint32_t)((((int64_t)frame * (a.tokens - 1) + tok - 1) * D + (nb - (which - a.qkv_first) * D) + dc * 8) * 2);
-            __builtin_amdgcn_raw_buffer_store_b128(d, which == 2 ? srdV : srdK, off, 0, 0);
-          }
+          uint32_t off = rloc < rows_left ? cbase + (uint32_t)rloc * (uint32_t)(a.ldc * 2) : 0xffffffffu;  // out of range: dropped
+          if (LABP_NO_STORE) off = d.x == 0x12345678 ? off : 0xffffffffu;
+          store_out(d, srdC, off, a.stream_out);
         }
       }
     }
     if (!has_next) break;
-    s_prev = 16 * passes;
+    s_prev = stores;
     par = (par + nk) & 1;
     idx = nidx;
     cur = nxt;
@@ -378,7 +424,9 @@ int launch256p(const GemmArgs& a, hipStream_t st) {
     n_cu = prop.multiProcessorCount;
   }
   const int64_t ntiles = (int64_t)tiles_m * tiles_n;
-  const int grid = (int)(ntiles < n_cu ? ntiles : n_cu);
+  int cus = n_cu - a.spare_cus;
+  cus = cus < n_cu / 2 ? n_cu / 2 : cus;
+  const int grid = (int)(ntiles < cus ? ntiles : cus);
   hipLaunchKernelGGL((gemm256p_kernel<EPI>), dim3(grid), dim3(512), 0, st, a, tiles_m, tiles_n);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -406,11 +454,16 @@ int DFD_GEMM256P_TRY(const GemmArgs& a, int c_dtype, int epi, hipStream_t st) {
       return launch256p<DFD_EPI_BIAS>(a, st);
     case DFD_EPI_BIAS_QUICKGELU:
       return launch256p<DFD_EPI_BIAS_QUICKGELU>(a, st);
-    case DFD_EPI_QKV_EXPORT:
+    case DFD_EPI_QKV_EXPORT: {
       if ((a.N / (3 - a.qkv_first)) % TN != 0) return 1;
       if (a.pos && (reinterpret_cast<uintptr_t>(a.pos) & 15) != 0) return 1;
       if (a.k_export && (a.M / a.tokens) * (a.tokens - 1) * (int64_t)(a.N / (3 - a.qkv_first)) * 2 > lim) return 1;
-      return launch256p<DFD_EPI_QKV_EXPORT>(a, st);
+      if (a.M >= ((int64_t)1 << 31)) return 1;
+      GemmArgs b = a;
+      b.div_tokens = FastDiv::make((uint32_t)a.tokens);
+      b.div_frames = FastDiv::make((uint32_t)a.frames_per_clip);
+      return launch256p<DFD_EPI_QKV_EXPORT>(b, st);
+    }
     default:
       return 1;
   }

@@ -2,6 +2,19 @@
 #pragma once
 #include "dropout.hpp"
 
+// floor(n / d) for 0 <= n < 2^31 as one multiply-high and a shift: mul = ceil(2^(31+s) / d), s = ceil(log2 d)
+struct FastDiv {
+  uint32_t mul, shift, one;
+  static FastDiv make(uint32_t d) {
+    if (d <= 1) return FastDiv{0u, 0u, 1u};
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    const uint64_t m = ((1ull << (31 + s)) + d - 1) / d;
+    return FastDiv{(uint32_t)m, s - 1, 0u};
+  }
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return one ? n : (__umulhi(n, mul) >> shift); }
+};
+
 struct GemmArgs {
   const void* A;
   const void* W;
@@ -15,7 +28,10 @@ struct GemmArgs {
   int64_t lda, ldw, ldc, M;
   int N, K, tokens, frames_per_clip;
   int qkv_first;  // QKV_EXPORT: first column block present (0 = q, 1 = k)
+  int stream_out; // DFD_GEMM_STREAM_OUT: non-temporal output stores
+  int spare_cus;  // persistent kernel: compute units left free for other streams
   DfdDrop drop;   // RESIDUAL_POS: dropout on the accumulator (element index row*N + col); thr16 == 0: none
+  FastDiv div_tokens, div_frames;  // persistent kernel, QKV_EXPORT: row -> (frame, token), frame -> frame % T
 };
 
 // tuned bf16 kernels: 0 = launched, <0 = error, 1 = shape / epilogue not eligible

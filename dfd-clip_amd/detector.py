@@ -239,6 +239,7 @@ class Detector(RuntimeStateMixin, nn.Module):
         # the clips handed to forward() are already complete in device memory
         self.pipeline_encoder = False
         self.inputs_ready = False
+        self.pipeline_spare_cus = None  # None = one compute unit per shader engine (CUs / 8), see `_encode`
         self._enc_stream = None
         self._pipe_events = [[], []]
         self._pipe_step = 0
@@ -340,8 +341,20 @@ class Detector(RuntimeStateMixin, nn.Module):
             pos_ready = torch.cuda.Event()
             pos_ready.record(cur)
             pos = snap
-        with torch.cuda.stream(E):
-            kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos, out=out, pos_ready=pos_ready)
+        # While a training step's backward / optimizer is what runs beside this pass, the persistent GEMMs leave one
+        # compute unit per shader engine free (MI355X: 32 of 256): the ~450 small dependent kernels of the decoder then
+        # never wait for a whole GEMM to end.  Measured (B16xT30 train step): 0-30 spare CUs 22.4-22.8 ms, 32-34 spare
+        # 20.9-21.0 ms, 40+ 22.0 ms (the encoder loses more than the overlap returns) — the workgroup dispatcher deals
+        # workgroups to shader engines in turn, so a small kernel stalls as soon as ONE engine has no free CU.
+        spare = self.pipeline_spare_cus
+        if spare is None:
+            spare = torch.cuda.get_device_properties(x.device).multi_processor_count // 8
+        self.encoder.spare_cus = spare if torch.is_grad_enabled() and self.training else 0
+        try:
+            with torch.cuda.stream(E):
+                kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos, out=out, pos_ready=pos_ready)
+        finally:
+            self.encoder.spare_cus = 0
         x.record_stream(E)
         cur.wait_stream(E)
         events = [torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()]  # forward, decoder bwd, adapter bwd

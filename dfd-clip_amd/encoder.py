@@ -129,6 +129,12 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         # bf16 path: residual branches are stored as bf16 deltas and added inside the next LayerNorm
         # (see `_residual`); the fp32 parity path keeps the read-modify-write epilogue
         self.deferred_residual = precision == "bf16"
+        # which GEMM outputs are stored non-temporally (capi.gemm stream_out): they are written once and read back only
+        # after other traffic has flushed the caches anyway, and keeping them out of L2 leaves the operand panels there
+        self.stream_out = {"qkv": True, "out": True, "fc": True, "proj": True}
+        # compute units the persistent GEMMs leave free (capi.gemm spare_cus): set by Detector while it overlaps the
+        # decoder's backward / optimizer of the previous step with this encoder pass
+        self.spare_cus = 0
 
     # ---- derived device-side operands ---------------------------------------------------
     @property
@@ -253,7 +259,7 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         if self.deferred_residual:
             pend = ws.get("pending", 0)
             assert pend < 2
-            capi.gemm(a, w, ws["delta2" if pend else "delta"], b, capi.EPI_BIAS, m=M)
+            capi.gemm(a, w, ws["delta2" if pend else "delta"], b, capi.EPI_BIAS, m=M, stream_out=self.stream_out["proj" if pend else "out"], spare_cus=self.spare_cus)
             ws["pending"] = pend + 1
         else:
             capi.gemm(a, w, ws["x"], b, capi.EPI_BIAS_RESIDUAL, m=M)
@@ -277,18 +283,22 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
             # last tapped layer: only its K and V are read, so the query third of the projection is skipped too
             D = self.width
             capi.gemm(h, bp["w_qkv"][D:], qkv[:, D:], bp["b_qkv"][D:], capi.EPI_QKV_EXPORT, m=M, pos=export[2],
-                      k_export=export[0], v_export=export[1], tokens=self.tokens, frames_per_clip=export[3], qkv_first=1)
+                      k_export=export[0], v_export=export[1], tokens=self.tokens, frames_per_clip=export[3], qkv_first=1,
+                      stream_out=self.stream_out["qkv"], spare_cus=self.spare_cus)
         elif export is not None:
             capi.gemm(h, bp["w_qkv"], qkv, bp["b_qkv"], capi.EPI_QKV_EXPORT, m=M, pos=export[2], k_export=export[0],
-                      v_export=export[1], tokens=self.tokens, frames_per_clip=export[3])
+                      v_export=export[1], tokens=self.tokens, frames_per_clip=export[3], stream_out=self.stream_out["qkv"],
+                      spare_cus=self.spare_cus)
         else:
-            capi.gemm(h, bp["w_qkv"], qkv, bp["b_qkv"], capi.EPI_QKV_EXPORT, m=M, tokens=self.tokens)
+            capi.gemm(h, bp["w_qkv"], qkv, bp["b_qkv"], capi.EPI_QKV_EXPORT, m=M, tokens=self.tokens, stream_out=self.stream_out["qkv"],
+                      spare_cus=self.spare_cus)
         if kv_only:
             return
         capi.attention_fwd(qkv, ws["mix"], n, self.tokens, self.heads)
         self._residual(ws, ws["mix"], bp["w_out"], bp["b_out"], M)
         self._ln(ws, bp["ln2"], M, store=False)
-        capi.gemm(h, bp["w_fc"], ws["u"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M)
+        capi.gemm(h, bp["w_fc"], ws["u"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M, stream_out=self.stream_out["fc"],
+                  spare_cus=self.spare_cus)
         self._residual(ws, ws["u"], bp["w_proj"], bp["b_proj"], M)
 
     @torch.no_grad()

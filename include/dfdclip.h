@@ -74,7 +74,18 @@ typedef struct dfd_gemm_extra {
   const uint64_t* drop_rng; /* RESIDUAL_POS: dropout on acc before the residual add (the adapter's last nn.Dropout,   */
   uint32_t drop_site;       /* models.py:807 etc.): C = residual + dropout(acc) + pos; element index = row*N + col;  */
   float drop_p;             /* drop_rng NULL or drop_p 0 = none                                                      */
+  uint32_t flags;           /* DFD_GEMM_* bits */
 } dfd_gemm_extra;
+
+/* dfd_gemm_extra.flags */
+enum {
+  DFD_GEMM_STREAM_OUT = 1,  /* C (and the K/V export) is written once and not re-read soon by this GPU's caches' standards:
+                               store it non-temporally so that it does not evict the operand panels from L2 (tuned bf16
+                               kernels; ignored elsewhere) */
+  DFD_GEMM_SPARE_CUS_SHIFT = 8 /* bits 8..15: compute units the persistent kernel leaves free (its grid is one workgroup
+                               per remaining CU), so that small latency-bound kernels of ANOTHER stream — the decoder's
+                               backward and the optimizer while the next batch's encoder pass runs — find a CU at once */
+};
 
 const char* dfd_last_error(void);          /* host pointer, valid until the thread's next failing call */
 int dfd_abi_version(void);
