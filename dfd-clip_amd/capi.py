@@ -233,7 +233,7 @@ def profile_gemm_collect():
 
 
 def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_export=None, v_export=None, tokens=0,
-         frames_per_clip=0, residual=None, qkv_first=0, drop=None, stream_out=False, spare_cus=0):
+         frames_per_clip=0, residual=None, qkv_first=0, drop=None, stream_out=False, spare_cus=0, tile_blocks=0):
     """c = epilogue(a[M,K] @ w[N,K]^T).  `m` limits the rows used (buffers may be over-allocated)."""
     _dev(a, w, c, bias, pos, cls, k_export, v_export, residual)
     assert a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1 and c.stride(1) == 1
@@ -244,7 +244,7 @@ def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_ex
     assert drop is None or epilogue == EPI_RESIDUAL_POS
     extra = GemmExtra(_ptr(pos).value, _ptr(cls).value, _ptr(k_export).value, _ptr(v_export).value, tokens, frames_per_clip,
                       _ptr(residual).value, qkv_first, drop.rng.data_ptr() if drop is not None and drop.p > 0 else None,
-                      drop.site if drop is not None else 0, drop.p if drop is not None else 0.0, (GEMM_STREAM_OUT if stream_out else 0) | ((int(spare_cus) & 0xff) << 8))
+                      drop.site if drop is not None else 0, drop.p if drop is not None else 0.0, (GEMM_STREAM_OUT if stream_out else 0) | ((int(spare_cus) & 0xff) << 8) | ((int(tile_blocks) & 0xf) << 16))
     timed = _profile["epilogue"] == epilogue
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

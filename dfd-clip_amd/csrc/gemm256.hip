@@ -29,32 +29,6 @@
 
 #include "gemm_args.hpp"
 
-// Lab switches (tools/lab/gemm_lab.hip builds ablated variants of this file; never set in the product)
-#ifndef LAB_NO_GLDS
-#define LAB_NO_GLDS 0
-#endif
-#ifndef LAB_NO_DSREAD
-#define LAB_NO_DSREAD 0
-#endif
-#ifndef LAB_NO_BARRIER
-#define LAB_NO_BARRIER 0
-#endif
-#ifndef LAB_NO_EPILOGUE
-#define LAB_NO_EPILOGUE 0
-#endif
-#ifndef LAB_SAME_TILE
-#define LAB_SAME_TILE 0
-#endif
-#ifndef LAB_NO_STORE
-#define LAB_NO_STORE 0
-#endif
-#ifndef LAB_NO_GELU
-#define LAB_NO_GELU 0
-#endif
-#ifndef DFD_GEMM256_TRY
-#define DFD_GEMM256_TRY dfd_gemm256_try
-#endif
-
 namespace {
 
 constexpr int TM = 256, TN = 256, TK = 64;
@@ -64,25 +38,9 @@ constexpr int SLOT = (TM + TN) * ROWB;    // 64 KB
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-#if !LAB_NO_GLDS
-  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
-#endif
-}
-__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) {
-#if LAB_NO_DSREAD
-  bf16x8 v;
-  asm volatile("" : "=v"(v));
-  return v;
-#else
-  return *reinterpret_cast<const bf16x8*>(p);
-#endif
-}
-__device__ __forceinline__ void wg_barrier() {
-#if !LAB_NO_BARRIER
-  __builtin_amdgcn_s_barrier();
-#endif
-}
+__device__ __forceinline__ void glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0); }
+__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void wg_barrier() { __builtin_amdgcn_s_barrier(); }
 
 template <typename CT, int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tiles_n) {
@@ -120,10 +78,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
   for (int p = 0; p < 4; ++p) {
     const int r = wave * 32 + p * 8 + prow;
     const int chunk = ppos ^ ((r >> 1) & 7);
-    int64_t am = (LAB_SAME_TILE ? 0 : m0) + r;
+    int64_t am = m0 + r;
     am = am < a.M ? am : a.M - 1;
     ga[p] = static_cast<const unsigned char*>(a.A) + (am * a.lda) * 2 + chunk * 16;
-    gw[p] = static_cast<const unsigned char*>(a.W) + ((int64_t)((LAB_SAME_TILE ? 0 : n0) + r) * a.ldw) * 2 + chunk * 16;
+    gw[p] = static_cast<const unsigned char*>(a.W) + ((int64_t)(n0 + r) * a.ldw) * 2 + chunk * 16;
   }
   auto issue_a = [&](int kt) {
     unsigned char* d = smem + (kt & 1) * SLOT + wave * 32 * ROWB;
@@ -220,17 +178,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
     });
   }
 
-#if LAB_NO_EPILOGUE
-  {
-    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) t += acc[i][j];
-    if (t[0] == 123.456f) static_cast<float*>(a.C)[0] = t[1] + t[2] + t[3];
-    return;
-  }
-#endif
   // ---- LDS-staged epilogues -------------------------------------------------------------------------
   // The ring is dead now, so each wave owns 16 KB of it.  The wave parks its 128x64 patch there
   // (conflict-free XOR layouts) and reads it back row-contiguous: global traffic becomes whole
@@ -267,7 +214,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           f32x4 v = acc[i][j] + b4[j];
-          if constexpr (EPI == DFD_EPI_BIAS_QUICKGELU && !LAB_NO_GELU) {
+          if constexpr (EPI == DFD_EPI_BIAS_QUICKGELU) {
             // v * sigmoid(1.702 v) = v / (1 + 2^(-1.702*log2(e)*v)): the epilogue of this shape is VALU-bound
             // (two waves per SIMD, no MFMA left to hide behind), so the scale constants are folded into
             // one packed multiply and everything but v_exp_f32 / v_rcp_f32 stays in packed f32 ops
@@ -296,9 +243,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs a, int tile
         const int row = rr * 8 + (lane >> 3), c = lane & 7;
         const uint4 d = *reinterpret_cast<const uint4*>(ep + row * 128 + ((c ^ (row & 7)) << 4));
         const int64_t m = m0 + wr * 128 + row;
-        if (LAB_NO_STORE) {
-          if (d.x == 0x12345678u && d.y == 0x9abcdef0u) *reinterpret_cast<uint4*>(dst + m * a.ldc + nb + c * 8) = d;
-        } else if (m < a.M) {
+        if (m < a.M) {
           // stream_out: non-temporal stores, the output goes past L2 instead of evicting the operand panels the other
           // workgroups of the XCD are still reading (c_fc 0.486 -> 0.446 ms, QKV 0.361 -> 0.326 ms on MI355X)
           typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -496,7 +441,7 @@ int launch256(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
-int DFD_GEMM256_TRY(const GemmArgs& a, int c_dtype, int epi, hipStream_t st) {
+int dfd_gemm256_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st) {
   if (a.N % TN != 0 || a.K % 64 != 0 || a.K < 128 || a.M < 1024) return 1;
   if ((a.lda % 8) != 0 || (a.ldw % 8) != 0 || (a.ldc % 4) != 0) return 1;
   if ((reinterpret_cast<uintptr_t>(a.C) & 15) != 0) return 1;

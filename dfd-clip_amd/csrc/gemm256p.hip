@@ -21,37 +21,19 @@
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef v4i_t v4i;
 
-#ifndef LABP_NO_STORE
-#define LABP_NO_STORE 0
-#endif
-#ifndef LABP_NO_EPI
-#define LABP_NO_EPI 0
-#endif
-#ifndef LABP_STAGGER
-#define LABP_STAGGER 0
-#endif
-#ifndef LABP_STORE_AUX
-#define LABP_STORE_AUX -1  // -1: GemmArgs.stream_out decides (product); >= 0: fixed cache-policy bits (lab)
-#endif
-#ifndef DFD_GEMM256P_TRY
-#define DFD_GEMM256P_TRY dfd_gemm256p_try
-#endif
-
 namespace {
 
 // Output stores: non-temporal (aux bit 1) when the caller marks the output as streaming: it then goes past L2
 // instead of evicting the operand panels the XCD's other workgroups are reading (c_fc 0.46 -> 0.41 ms).
 __device__ __forceinline__ void store_out(v4i_t d, __amdgpu_buffer_rsrc_t srd, uint32_t off, int stream_out) {
-  if (LABP_STORE_AUX >= 0) {
-    __builtin_amdgcn_raw_buffer_store_b128(d, srd, off, 0, LABP_STORE_AUX < 0 ? 0 : LABP_STORE_AUX);
-  } else if (stream_out) {
+  if (stream_out) {
     __builtin_amdgcn_raw_buffer_store_b128(d, srd, off, 0, 2);
   } else {
     __builtin_amdgcn_raw_buffer_store_b128(d, srd, off, 0, 0);
   }
 }
 
-constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int TM = 256, TN = 256, TK = 64;  // TM: rows of A staged per step; a tile USES 32*RB of them (RB = 8 or 7)
 constexpr int ROWB = TK * 2;            // 128 B per LDS row = one cache line
 constexpr int A_BYTES = TM * ROWB;      // 32 KB
 constexpr int SLOT = (TM + TN) * ROWB;  // 64 KB
@@ -64,7 +46,7 @@ struct Tile {
 };
 
 // tile order: column GROUPS of at most 6 tiles, inside a group row panel major / column minor (gemm256.hip)
-__device__ __forceinline__ Tile decode_tile(int idx, int tiles_m, int tiles_n) {
+__device__ __forceinline__ Tile decode_tile(int idx, int tiles_m, int tiles_n, int tile_rows) {
   const int ngroups = (tiles_n + 5) / 6;
   const int gcols = (tiles_n + ngroups - 1) / ngroups;
   int grp = idx / (tiles_m * gcols);
@@ -72,13 +54,20 @@ __device__ __forceinline__ Tile decode_tile(int idx, int tiles_m, int tiles_n) {
   const int rem = idx - grp * tiles_m * gcols;
   const int cols_here = min(gcols, tiles_n - grp * gcols);
   const int tm = rem / cols_here, tn = grp * gcols + (rem - tm * cols_here);
-  return Tile{tm * TM, tn * TN};
+  return Tile{tm * tile_rows, tn * TN};
 }
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI>
+// RB = 16-row blocks per wave: 8 -> 256-row tiles; 7 -> 224-row tiles (the launcher picks the height whose tile count
+// divides best over the CUs: at M = 94,560 the 256-row grid needs 4.34 / 13.01 / 17.3 rounds of tiles for N = 768 /
+// 2304 / 3072, i.e. 5 / 14 / 18; 224-row tiles need 4.96 / 14.9 / 19.8 rounds of 7/8 the work).  The staging of A is
+// the same for both (256 rows: the extra 32 belong to the next tile and are simply not used).
+template <int EPI, int RB>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+  constexpr int TMU = 32 * RB;   // rows a tile uses
+  constexpr int WROWS = 16 * RB; // rows per wave
+  constexpr int HB = RB - 4;     // row blocks in the second half (phases P1 / P3)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[RING + 8 * STAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -143,7 +132,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
   int offA[2], offW[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    offA[ks] = (wr * 128 + fr) * ROWB + (((4 * ks + fq) ^ sw) << 4);
+    offA[ks] = (wr * WROWS + fr) * ROWB + (((4 * ks + fq) ^ sw) << 4);  // WROWS/2 is a multiple of 8: the swizzle term is unchanged
     offW[ks] = A_BYTES + (wc * 64 + fr) * ROWB + (((4 * ks + fq) ^ sw) << 4);
   }
   auto read_w = [&](bf16x8 (&w)[4], int slot, int ks) {
@@ -154,10 +143,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
   auto read_a = [&](bf16x8 (&f)[4], int slot, int ks, int half) {
     const unsigned char* sb = smem + slot * SLOT + offA[ks] + half * 64 * ROWB;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * ROWB);
+    for (int i = 0; i < 4; ++i)
+      if (half == 0 || i < HB) f[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * ROWB);
   };
 
-  f32x4 acc[8][4];
+  f32x4 acc[RB][4];
   auto phase = [&](const bf16x8 (&w)[4], const bf16x8 (&f)[4], int half, auto&& mid) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -168,20 +158,16 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 1; i < 4; ++i)
+    for (int i = 1; i < (half == 0 ? 4 : HB); ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[4 * half + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], f[i], acc[4 * half + i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  if (LABP_STAGGER) {
-    const int phase = (bid >> 3) & 7;
-    for (int i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(LABP_STAGGER);
-  }
   const int nk = a.K / TK;  // >= 2
   int idx = pos;            // < ntiles: the launcher keeps G <= ntiles
-  Tile cur = decode_tile(idx, tiles_m, tiles_n);
+  Tile cur = decode_tile(idx, tiles_m, tiles_n, TMU);
   set_a(cur);
   set_w(cur);
   int par = 0;  // ring slot of the current tile's step 0
@@ -210,9 +196,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
   for (;;) {
     const int nidx = idx + G;
     const bool has_next = nidx < ntiles;
-    const Tile nxt = has_next ? decode_tile(nidx, tiles_m, tiles_n) : cur;
+    const Tile nxt = has_next ? decode_tile(nidx, tiles_m, tiles_n, TMU) : cur;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     read_w(wA, par, 0);
@@ -259,8 +245,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (kt == 0) {
         if (s_prev == 0) wait_vm<0>();
-        else if (s_prev == 16) wait_vm<16>();
-        else wait_vm<32>();
+        else if (s_prev == 2 * RB) wait_vm<2 * RB>();
+        else wait_vm<4 * RB>();
       } else {
         wait_vm<0>();
       }
@@ -295,23 +281,16 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
     const int er = le & 15, eq = le >> 4;          // accumulator fragment: row er of a 16-row block, columns 4*eq ..
     const int drow = le >> 3, dc = le & 7;         // drain: row drow of an 8-row group, 16-byte chunk dc
     const int nb = cur.n0 + wc * 64;
-    const int64_t mrow0 = (int64_t)cur.m0 + wr * 128 + drow;  // first row this lane stores
+    const int64_t mrow0 = (int64_t)cur.m0 + wr * WROWS + drow;  // first row this lane stores
     const int rows_left = (int)min((int64_t)0x7fffffff, a.M - mrow0);
     int which = 0;
     if constexpr (EPI == DFD_EPI_QKV_EXPORT) which = cur.n0 / D + a.qkv_first;  // 0 = q, 1 = k, 2 = v
     const bool exporting = EPI == DFD_EPI_QKV_EXPORT && which > 0 && a.k_export != nullptr;
-    int stores = 16;
-    if (LABP_NO_EPI) {
-      f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) t += acc[i][j];
-      if (t[0] == 123.456f) static_cast<float*>(a.C)[0] = t[1] + t[2] + t[3] + b4[0][0] + b4[1][0] + b4[2][0] + b4[3][0];
-    } else {
+    int stores = 2 * RB;
+    {
       // bias once, in place: both copies of an exported tile read the same registers
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] += b4[j];
       if constexpr (EPI == DFD_EPI_QKV_EXPORT) {
@@ -320,12 +299,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
           // this tile's stores): bf16(acc + bias + pos[frame % T]) -> row frame*(tokens-1) + token-1 of the export,
           // the CLS row dropped.  Eight sub-passes of 16 rows parked as f32 (4 KB); the drain adds the embedding
           // (two 16-byte loads per store, requested at the top of the sub-pass) and rounds once.
-          stores = 32;
+          stores = 4 * RB;
           const int ecol = nb - (which - a.qkv_first) * D + dc * 8;  // first of this lane's 8 export columns
           unsigned char* const parkf = ep + er * 256;                 // unit (j*4 + eq) ^ er of a 256-byte row
           const __amdgpu_buffer_rsrc_t srdE = which == 2 ? srdV : srdK;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
+          for (int i = 0; i < RB; ++i) {
             __builtin_amdgcn_sched_barrier(0);  // keep each sub-pass's embedding loads inside it (16 registers, not 128)
             uint32_t eoff[2];
             f32x4 pe[2][2];
@@ -369,6 +348,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
           const int i = 2 * q + ii;
+          if (i >= RB) continue;  // 224-row tiles: the last pass holds 16 rows
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             f32x4 v = acc[i][j];
@@ -393,10 +373,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
         }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
+          if (q * 32 + rr * 8 >= WROWS) continue;
           const v4i d = *reinterpret_cast<const v4i*>(dsrc + rr * 1024);
           const int rloc = q * 32 + rr * 8;  // row of the store relative to this lane's first row
           uint32_t off = rloc < rows_left ? cbase + (uint32_t)rloc * (uint32_t)(a.ldc * 2) : 0xffffffffu;  // out of range: dropped
-          if (LABP_NO_STORE) off = d.x == 0x12345678 ? off : 0xffffffffu;
           store_out(d, srdC, off, a.stream_out);
         }
       }
@@ -412,7 +392,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
 template <int EPI>
 int launch256p(const GemmArgs& a, hipStream_t st) {
   const int tiles_n = a.N / TN;
-  const int tiles_m = (int)((a.M + TM - 1) / TM);
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -423,11 +402,23 @@ int launch256p(const GemmArgs& a, hipStream_t st) {
     }
     n_cu = prop.multiProcessorCount;
   }
-  const int64_t ntiles = (int64_t)tiles_m * tiles_n;
   int cus = n_cu - a.spare_cus;
   cus = cus < n_cu / 2 ? n_cu / 2 : cus;
+  // tile height: the one with the least (rounds of tiles) x (cost of a tile).  A 224-row tile saves the MFMA and
+  // epilogue work of 32 rows but stages as many bytes as a 256-row one, and the loop is bound by that staging:
+  // measured on the four ViT-B/16 shapes it costs 0.97 of a full tile, so it wins only where it saves a whole
+  // round (M = 94,560: N = 768 needs 5 rounds either way -> 224; N = 2304 / 3072: 15 vs 14, 20 vs 18 -> 256)
+  auto rounds = [&](int rows) {
+    const int64_t tiles = ((a.M + rows - 1) / rows) * tiles_n;
+    return (double)((tiles + cus - 1) / cus);
+  };
+  const bool use224 = a.tile_rows == 224 || (a.tile_rows == 0 && rounds(224) * 0.97 < rounds(256));
+  const int rows = use224 ? 224 : 256;
+  const int tiles_m = (int)((a.M + rows - 1) / rows);
+  const int64_t ntiles = (int64_t)tiles_m * tiles_n;
   const int grid = (int)(ntiles < cus ? ntiles : cus);
-  hipLaunchKernelGGL((gemm256p_kernel<EPI>), dim3(grid), dim3(512), 0, st, a, tiles_m, tiles_n);
+  if (use224) hipLaunchKernelGGL((gemm256p_kernel<EPI, 7>), dim3(grid), dim3(512), 0, st, a, tiles_m, tiles_n);
+  else hipLaunchKernelGGL((gemm256p_kernel<EPI, 8>), dim3(grid), dim3(512), 0, st, a, tiles_m, tiles_n);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     dfd_set_error("dfd_gemm(persistent bf16): launch failed: %s", hipGetErrorString(e));
@@ -439,7 +430,7 @@ int launch256p(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 // 0 = launched, <0 = error, 1 = shape / epilogue not served by this kernel
-int DFD_GEMM256P_TRY(const GemmArgs& a, int c_dtype, int epi, hipStream_t st) {
+int dfd_gemm256p_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st) {
   if (c_dtype != DFD_BF16) return 1;
   if (a.N % TN != 0 || a.K % 64 != 0 || a.K < 128 || a.M < 1024) return 1;
   if ((a.lda % 8) != 0 || (a.ldw % 8) != 0 || (a.ldc % 8) != 0) return 1;

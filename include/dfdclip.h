@@ -82,6 +82,8 @@ enum {
   DFD_GEMM_STREAM_OUT = 1,  /* C (and the K/V export) is written once and not re-read soon by this GPU's caches' standards:
                                store it non-temporally so that it does not evict the operand panels from L2 (tuned bf16
                                kernels; ignored elsewhere) */
+  DFD_GEMM_TILE_BLOCKS_SHIFT = 16, /* bits 16..19: 0 = the persistent kernel chooses its tile height; 7 / 8 = force 224- /
+                               256-row tiles (tests, tuning) */
   DFD_GEMM_SPARE_CUS_SHIFT = 8 /* bits 8..15: compute units the persistent kernel leaves free (its grid is one workgroup
                                per remaining CU), so that small latency-bound kernels of ANOTHER stream — the decoder's
                                backward and the optimizer while the next batch's encoder pass runs — find a CU at once */

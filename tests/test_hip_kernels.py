@@ -238,6 +238,50 @@ def test_gemm_tuned_kernel_every_epilogue(capi, M, N, K):
             assert torch.equal(ke2, ke) and torch.equal(ve2, ve) and torch.equal(cq2[:, D:], cq[:, D:])
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(94560, 768, 768, "bias"), (20000, 2304, 768, "qkv"), (70000, 3072, 768, "gelu"), (5000, 1024, 4096, "bias")])
+def test_persistent_gemm_variants_are_bit_identical(capi, M, N, K, epi):
+    """The persistent kernel's knobs change scheduling, never arithmetic: 224- vs 256-row tiles, non-temporal output
+    stores, compute units left to other streams and the automatic choice all give the same bits, at sizes with
+    several rounds of tiles per CU (ragged last row panel, last round partly empty)."""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    kw, e = {}, capi.EPI_BIAS
+    tokens, T = 197, 5
+    if epi == "gelu":
+        e = capi.EPI_BIAS_QUICKGELU
+    if epi == "qkv":
+        e = capi.EPI_QKV_EXPORT
+        M = M // tokens * tokens
+        a = a[:M]
+        D = N // 3
+        kw = dict(pos=torch.randn(T, D, device="cuda", generator=g), tokens=tokens, frames_per_clip=T)
+
+    def run(**opts):
+        c = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ex = {}
+        if epi == "qkv":
+            ex = dict(k_export=torch.full((M // tokens * (tokens - 1), N // 3), float("nan"), device="cuda", dtype=torch.bfloat16))
+            ex["v_export"] = torch.full_like(ex["k_export"], float("nan"))
+        capi.gemm(a, w, c, bias, e, **kw, **ex, **opts)
+        assert capi.gemm_last_path() == 256
+        return [c] + list(ex.values())
+
+    base = run(tile_blocks=8)
+    rows = torch.randint(0, M, (2048,), device="cuda", generator=g)
+    ref = a[rows].double() @ w.double().T + bias.double()
+    if epi == "gelu":
+        ref = ref * torch.sigmoid(1.702 * ref)
+    assert_close(base[0][rows], ref, 1e-4, 2 ** -8, "256-row tiles")
+    assert all(torch.isfinite(t.float()).all() for t in base), "a tile or an export row was not written"
+    for opts in (dict(tile_blocks=7), dict(), dict(tile_blocks=8, stream_out=True), dict(tile_blocks=7, stream_out=True, spare_cus=32),
+                 dict(spare_cus=100)):
+        got = run(**opts)
+        for x, y in zip(base, got):
+            assert torch.equal(x, y), opts
+
+
 @pytest.mark.parametrize("res,patch,width", [(224, 16, 768), (224, 14, 1024)])
 def test_patch_embed_tuned_kernel(capi, res, patch, width):
     """PATCH_EMBED epilogue of the tuned kernel (M = frames*P >= 1024): conv1 + CLS row + positional embedding at
