@@ -162,12 +162,14 @@ def main():
     y = (torch.arange(B, device=device) % 2)
     from dfd_clip_amd import dist as ddist
     ddist.broadcast_parameters(det)
-    # the ~450 small decoder launches of a train step replay as two HIP graphs (forward / backward kernels):
-    # the host then enqueues a step in a few ms instead of ~14, which keeps the step GPU-bound on a busy host
-    # (graphs stay off at world > 1: with two ranks sharing one GPU — the only multi-process rehearsal available to
-    # this repo — graph replay + the pipelined encoder + a collective stalled for seconds per step, while either
-    # of them alone ran normally; untested on a real multi-GPU node, so the safe pair is used there)
-    det.static_graphs = (not args.no_graphs) and world == 1
+    # the ~450 small decoder launches of a train step replay as two HIP graphs (forward / backward kernels): the host then
+    # enqueues a step in a few ms instead of ~14, which keeps the step GPU-bound on a busy host.  Round 1 saw
+    # multi-second steps with graphs + pipelining in a two-ranks-on-one-GPU gloo rehearsal and switched graphs off at
+    # world > 1; round 2 re-ran that rehearsal five times in three variants without a single slow step and with the
+    # device draining every queued step in 22-27 ms (host-side, box-dependent, not a stream/event cycle),
+    # so graphs are on everywhere — guarded: the warm-up below times a few steps and every rank falls back to eager
+    # launches together if graphs make a step pathologically slow on this machine.
+    det.static_graphs = not args.no_graphs
     # the frozen encoder runs on its own stream: step N+1's encoder pass overlaps step N's decoder backward,
     # gradient all-reduce and optimizer step (the inputs are resident before the timed region: inputs_ready)
     det.pipeline_encoder = not args.no_pipeline
@@ -221,6 +223,22 @@ def main():
     step = train_step if args.mode == "train" else infer_step
     for _ in range(args.warmup):
         step()
+    graph_note = None
+    if world > 1 and det.static_graphs and args.mode == "train":
+        # guard (see above): two more untimed steps, host-synchronised; > 10x the single-GPU step time on any rank
+        # switches every rank to eager decoder launches
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        slow = torch.tensor([(time.perf_counter() - t0) / 2], device=device, dtype=torch.float64)
+        dist.all_reduce(slow, op=dist.ReduceOp.MAX)
+        if slow.item() > 0.25:
+            det.static_graphs = False
+            graph_note = f"HIP graphs switched off: {slow.item() * 1e3:.0f} ms/step with graphs at world {world}"
+            for _ in range(2):
+                step()
     dt, spans = timed(step, args.steps, True)
     host_enqueue_ms, host_cpu_ms = host_ms
     fwd_only = None
@@ -271,6 +289,8 @@ def main():
                          "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,
                          "launches_timed": len(spans), "avg_launch_ms": round(avg_ms, 4)},
         }
+        if graph_note:
+            line["config"]["note"] = graph_note
         if fwd_only is not None:
             line["forward_only"] = {"value": round(fwd_only, 3), "unit": "clips/s", "workload": "BASELINE configs[1]: Detector.predict"}
         if world == 1 and not args.no_cpu_baseline:
