@@ -69,6 +69,8 @@ SIGNATURES = {
     "dfd_preprocess_geometry": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "dfd_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int,
                          POINTER(GemmExtra), c_int64, c_int, c_int, c_void_p]),
+    "dfd_gemm_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float, c_int,
+                             POINTER(GemmExtra), c_int64, c_int, c_int, c_void_p]),
     "dfd_gemm_at_b_workspace": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "dfd_gemm_at_b": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "dfd_adapter_norm_gelu": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
@@ -251,6 +253,36 @@ def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_ex
         e0.record()
     _check(load_library().dfd_gemm(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _DTYPE[a.dtype], _ptr(c), c.stride(0),
                                    _DTYPE[c.dtype], _ptr(bias), epilogue, ctypes.byref(extra), M, N, K, _stream()), "dfd_gemm")
+    if timed:
+        e1.record()
+        _profile["events"].append((e0, e1, 2.0 * M * N * K))
+    return c
+
+
+FP8 = 2
+FP8_MAX = 448.0  # largest finite e4m3 value
+
+
+def gemm_fp8(a, w, c, col_scale, bias=None, epilogue=EPI_BIAS, m=None, out_inv_scale=0.0, pos=None, k_export=None, v_export=None,
+             tokens=0, frames_per_clip=0, qkv_first=0, stream_out=False, spare_cus=0):
+    """c = epilogue((a[M,K] @ w[N,K]^T) * col_scale + bias) on e4m3 operands (uint8 / float8_e4m3fn storage);
+    c bf16, or e4m3 bytes of result * out_inv_scale."""
+    _dev(a, w, c, col_scale, bias, pos, k_export, v_export)
+    assert a.element_size() == 1 and w.element_size() == 1 and a.stride(1) == 1 and w.stride(1) == 1 and c.stride(1) == 1
+    assert col_scale.dtype == torch.float32 and col_scale.is_contiguous()
+    M = a.shape[0] if m is None else m
+    N, K = w.shape
+    assert a.shape[1] == K and col_scale.numel() == N
+    c_dtype = FP8 if c.element_size() == 1 else _DTYPE[c.dtype]
+    extra = GemmExtra(_ptr(pos).value, None, _ptr(k_export).value, _ptr(v_export).value, tokens, frames_per_clip, None, qkv_first,
+                      None, 0, 0.0, (GEMM_STREAM_OUT if stream_out else 0) | ((int(spare_cus) & 0xff) << 8))
+    timed = _profile["epilogue"] == epilogue
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _check(load_library().dfd_gemm_fp8(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(c), c.stride(0), c_dtype, _ptr(col_scale),
+                                       _ptr(bias), float(out_inv_scale), epilogue, ctypes.byref(extra), M, N, K, _stream()),
+           "dfd_gemm_fp8")
     if timed:
         e1.record()
         _profile["events"].append((e0, e1, 2.0 * M * N * K))

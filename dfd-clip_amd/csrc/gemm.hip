@@ -275,24 +275,8 @@ int launch_at_b(const void* A, int64_t lda, const void* B, int64_t ldb, float* C
 
 }  // namespace
 
-static thread_local int g_last_path = 0;
-extern "C" int dfd_gemm_last_path(void) { return g_last_path; }
-
-extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int ab_dtype, void* C, int64_t ldc,
-                        int c_dtype, const float* bias, int epilogue, const dfd_gemm_extra* extra, int64_t M, int N,
-                        int K, void* stream) {
-  DFD_REQUIRE(A && W && C, "dfd_gemm: null pointer");
-  DFD_REQUIRE(M >= 0 && N > 0 && K > 0, "dfd_gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
-  DFD_REQUIRE(ab_dtype == DFD_F32 || ab_dtype == DFD_BF16, "dfd_gemm: ab_dtype=%d", ab_dtype);
-  DFD_REQUIRE(c_dtype == DFD_F32 || c_dtype == DFD_BF16, "dfd_gemm: c_dtype=%d", c_dtype);
-  DFD_REQUIRE(!(ab_dtype == DFD_F32 && c_dtype == DFD_BF16), "dfd_gemm: f32 operands with bf16 output unsupported");
-  DFD_REQUIRE(K % 32 == 0, "dfd_gemm: K=%d must be a multiple of 32", K);
-  const int esz = ab_dtype == DFD_F32 ? 4 : 2;
-  DFD_REQUIRE(lda >= K && ldw >= K && (lda * esz) % 16 == 0 && (ldw * esz) % 16 == 0, "dfd_gemm: lda=%lld ldw=%lld must be >= K and 16-byte multiples", (long long)lda, (long long)ldw);
-  DFD_REQUIRE(dfd_aligned16(A) && dfd_aligned16(W), "dfd_gemm: A and W must be 16-byte aligned");
-  GemmArgs a{};
-  a.A = A; a.W = W; a.C = C; a.bias = bias;
-  a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+// epilogue-specific argument checks + copy of dfd_gemm_extra into the kernels' argument block
+static int fill_extra(GemmArgs& a, int epilogue, const dfd_gemm_extra* extra, int c_dtype, int64_t ldc, int64_t M, int N) {
   if (epilogue == DFD_EPI_PATCH_EMBED) {
     DFD_REQUIRE(extra && extra->pos && extra->cls && extra->tokens > 1, "dfd_gemm: PATCH_EMBED needs extra.pos, extra.cls, extra.tokens");
     DFD_REQUIRE(M % (extra->tokens - 1) == 0, "dfd_gemm: PATCH_EMBED M=%lld is not a whole number of frames", (long long)M);
@@ -326,6 +310,28 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
       a.drop = dfd_make_drop(&dd);
     }
   }
+  return DFD_OK;
+}
+
+static thread_local int g_last_path = 0;
+extern "C" int dfd_gemm_last_path(void) { return g_last_path; }
+
+extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int ab_dtype, void* C, int64_t ldc,
+                        int c_dtype, const float* bias, int epilogue, const dfd_gemm_extra* extra, int64_t M, int N,
+                        int K, void* stream) {
+  DFD_REQUIRE(A && W && C, "dfd_gemm: null pointer");
+  DFD_REQUIRE(M >= 0 && N > 0 && K > 0, "dfd_gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+  DFD_REQUIRE(ab_dtype == DFD_F32 || ab_dtype == DFD_BF16, "dfd_gemm: ab_dtype=%d", ab_dtype);
+  DFD_REQUIRE(c_dtype == DFD_F32 || c_dtype == DFD_BF16, "dfd_gemm: c_dtype=%d", c_dtype);
+  DFD_REQUIRE(!(ab_dtype == DFD_F32 && c_dtype == DFD_BF16), "dfd_gemm: f32 operands with bf16 output unsupported");
+  DFD_REQUIRE(K % 32 == 0, "dfd_gemm: K=%d must be a multiple of 32", K);
+  const int esz = ab_dtype == DFD_F32 ? 4 : 2;
+  DFD_REQUIRE(lda >= K && ldw >= K && (lda * esz) % 16 == 0 && (ldw * esz) % 16 == 0, "dfd_gemm: lda=%lld ldw=%lld must be >= K and 16-byte multiples", (long long)lda, (long long)ldw);
+  DFD_REQUIRE(dfd_aligned16(A) && dfd_aligned16(W), "dfd_gemm: A and W must be 16-byte aligned");
+  GemmArgs a{};
+  a.A = A; a.W = W; a.C = C; a.bias = bias;
+  a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  { const int rc = fill_extra(a, epilogue, extra, c_dtype, ldc, M, N); if (rc != DFD_OK) return rc; }
   if (M == 0) return DFD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (ab_dtype == DFD_BF16) {
@@ -342,6 +348,31 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
   if (ab_dtype == DFD_F32) return launch_gemm128<float, float>(a, epilogue, st);
   if (c_dtype == DFD_BF16) return launch_gemm128<bf16_t, bf16_t>(a, epilogue, st);
   return launch_gemm128<bf16_t, float>(a, epilogue, st);
+}
+
+extern "C" int dfd_gemm_fp8(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int c_dtype,
+                            const float* col_scale, const float* bias, float out_inv_scale, int epilogue,
+                            const dfd_gemm_extra* extra, int64_t M, int N, int K, void* stream) {
+  DFD_REQUIRE(A && W && C && col_scale, "dfd_gemm_fp8: null pointer");
+  DFD_REQUIRE(M >= 0 && N > 0 && K > 0, "dfd_gemm_fp8: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+  DFD_REQUIRE(c_dtype == DFD_BF16 || c_dtype == DFD_FP8, "dfd_gemm_fp8: c_dtype=%d", c_dtype);
+  DFD_REQUIRE(epilogue == DFD_EPI_BIAS || epilogue == DFD_EPI_BIAS_QUICKGELU || epilogue == DFD_EPI_QKV_EXPORT,
+              "dfd_gemm_fp8: epilogue %d not served (BIAS, BIAS_QUICKGELU, QKV_EXPORT)", epilogue);
+  DFD_REQUIRE(c_dtype == DFD_BF16 || (epilogue != DFD_EPI_QKV_EXPORT && out_inv_scale > 0.f), "dfd_gemm_fp8: fp8 output needs out_inv_scale > 0 and a plain / QuickGELU epilogue");
+  DFD_REQUIRE(lda >= K && ldw >= K && ldc >= N, "dfd_gemm_fp8: leading dimensions");
+  GemmArgs a{};
+  a.A = A; a.W = W; a.C = C; a.bias = bias; a.col_scale = col_scale; a.out_inv_scale = out_inv_scale;
+  a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  { const int rc = fill_extra(a, epilogue, extra, c_dtype, ldc, M, N); if (rc != DFD_OK) return rc; }
+  if (M == 0) return DFD_OK;
+  const int epi_p = epilogue == DFD_EPI_QKV_EXPORT && a.k_export == nullptr ? DFD_EPI_BIAS : epilogue;
+  const int rc = dfd_gemm256p_f8_try(a, c_dtype, epi_p, static_cast<hipStream_t>(stream));
+  if (rc == 1) {
+    dfd_set_error("dfd_gemm_fp8: shape not served (needs M >= 1024, N %% 256 == 0, K %% 128 == 0, K >= 256, 16-byte aligned rows; got M=%lld N=%d K=%d)",
+                  (long long)M, N, K);
+    return DFD_ERR_INVALID_ARG;
+  }
+  return rc;
 }
 
 // gemm_tn.hip: bf16 operands read through the transposing LDS load, no HBM transposes

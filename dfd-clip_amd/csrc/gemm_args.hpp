@@ -33,8 +33,11 @@ struct GemmArgs {
   int tile_rows;  // persistent kernel: 0 = choose, 224 / 256 = force that tile height (lab, tests)
   DfdDrop drop;   // RESIDUAL_POS: dropout on the accumulator (element index row*N + col); thr16 == 0: none
   FastDiv div_tokens, div_frames;  // persistent kernel, QKV_EXPORT: row -> (frame, token), frame -> frame % T
+  const float* col_scale;          // fp8 operands: per output column, activation scale x weight-row scale
+  float out_inv_scale;             // fp8 output: stored value = e4m3(result * out_inv_scale)
 };
 
 // tuned bf16 kernels: 0 = launched, <0 = error, 1 = shape / epilogue not eligible
 int dfd_gemm256_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st);   // gemm256.hip: one workgroup per tile
 int dfd_gemm256p_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st);  // gemm256p.hip: persistent, bf16 C
+int dfd_gemm256p_f8_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st);  // same kernel, e4m3 operands (dfd_gemm_fp8)

@@ -22,7 +22,7 @@ extern "C" {
 
 #define DFD_ABI_VERSION 10
 
-enum { DFD_F32 = 0, DFD_BF16 = 1 };
+enum { DFD_F32 = 0, DFD_BF16 = 1, DFD_FP8 = 2 /* OCP e4m3 ("e4m3fn"), one byte per element */ };
 
 enum {
   DFD_OK = 0,
@@ -138,6 +138,17 @@ int dfd_preprocess_geometry(int in_h, int in_w, int res, int* rs_h, int* rs_w, i
 int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int ab_dtype, void* C, int64_t ldc,
              int c_dtype, const float* bias, int epilogue, const dfd_gemm_extra* extra, int64_t M, int N, int K,
              void* stream);
+/* The same product on OCP e4m3 ("fp8") operands, on the block-scaled matrix cores (v_mfma_scale_f32_16x16x128_f8f6f4,
+ * unit block scales; twice the bf16 rate): C = epilogue((A[M,K] · W[N,K]ᵀ) · col_scale[n] + bias[n]).  A, W: one byte per
+ * element, row-major (lda, ldw in elements); col_scale[n] = (scale the activations were divided by) x (scale row n of W was
+ * divided by); C bf16, or — plain and QuickGELU epilogues — e4m3 of result * out_inv_scale, saturated at +-448 (the c_fc
+ * output feeding the next fp8 GEMM).  Epilogues: BIAS, BIAS_QUICKGELU, QKV_EXPORT (exports bf16).  Served shapes:
+ * M >= 1024, N % 256 == 0, K % 128 == 0, K >= 256, 16-byte aligned rows; anything else is DFD_ERR_INVALID_ARG (there is
+ * no second fp8 kernel).  BASELINE configs[4]; quantisation policy: dfd-clip_amd/encoder.py. */
+int dfd_gemm_fp8(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int c_dtype,
+                 const float* col_scale, const float* bias, float out_inv_scale, int epilogue,
+                 const dfd_gemm_extra* extra, int64_t M, int N, int K, void* stream);
+
 /* Which kernel served this thread's last successful dfd_gemm: 256 = the tuned 256x256 bf16 kernel (M >= 1024,
  * N % 256 == 0, K % 64 == 0, K >= 128), 128 = the general 128x128 kernel, 0 = none yet.  For tests and profilers. */
 int dfd_gemm_last_path(void);
