@@ -33,6 +33,7 @@ import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3
+PEAK_FP8_TFLOPS = 5000.0   # dense, block-scaled e4m3 (same table)
 
 
 def parse():
@@ -43,7 +44,8 @@ def parse():
     ap.add_argument("--arch", default="ViT-B/16")
     ap.add_argument("--clips", type=int, default=16, help="clips per GPU per step")
     ap.add_argument("--frames", type=int, default=30)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="fp8 = BASELINE configs[4]: e4m3 operands for the encoder's q|k|v, c_fc and c_proj GEMMs (use with --arch ViT-L/14)")
     ap.add_argument("--frame-chunk", type=int, default=-1, help="frames per encoder pass (-1 = package default)")
     ap.add_argument("--streams", type=int, default=-1, help="HIP streams for independent frame chunks (-1 = package default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -219,6 +221,8 @@ def main():
             dt = tt.item()
         return dt, spans
 
+    if args.precision == "fp8":  # static activation scales from the synthetic batch itself, before anything is timed
+        det.calibrate_fp8(x[:2])
     det.train(args.mode == "train")
     step = train_step if args.mode == "train" else infer_step
     for _ in range(args.warmup):
@@ -263,7 +267,7 @@ def main():
         avg_ms = busy / max(1, len(spans))
         achieved = sum(fl for _, _, fl in spans) / (busy * 1e-3) / 1e12 if spans else None
         launch_m = int(round(spans[0][2] / (2.0 * 4 * width * width))) if spans else M
-        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        peak = {"bf16": PEAK_BF16_TFLOPS, "fp32": PEAK_F32_TFLOPS, "fp8": PEAK_FP8_TFLOPS}[args.precision]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
         if os.path.exists(tpath):  # PMC-measured HBM bytes per launch; only valid for the shape it was measured on

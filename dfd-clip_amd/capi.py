@@ -18,6 +18,8 @@ EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT
 ABI_VERSION = 10
 
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
+FP8 = 2           # ABI code of OCP e4m3; stored in uint8 / torch.float8_e4m3fn tensors
+FP8_MAX = 448.0   # largest finite e4m3 value
 
 
 class DfdError(RuntimeError):
@@ -60,9 +62,9 @@ SIGNATURES = {
     "dfd_gemm_last_path": (c_int, []),
     "dfd_dropout": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, POINTER(DropoutDesc), c_void_p]),
     "dfd_device_check": (c_int, []),
-    "dfd_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_float, c_void_p]),
+    "dfd_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_float, c_float, c_void_p]),
     "dfd_add_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
-                                  c_int, c_int64, c_int, c_float, c_void_p]),
+                                  c_int, c_int64, c_int, c_float, c_float, c_void_p]),
     "dfd_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dfd_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float),
                                   c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -153,25 +155,32 @@ def _dev(*tensors):
             raise DfdError("HIP kernels need device tensors; got a CPU tensor (there is no CPU path)")
 
 
-def layernorm(x, gamma, beta, out, eps=1e-5):
-    """out[rows, cols] = LayerNorm(x[rows, cols]); x f32; out f32 (may alias x) or bf16."""
+def _out_dtype(t):
+    """ABI dtype code of an output tensor: one-byte tensors (uint8 / float8_e4m3fn storage) are e4m3."""
+    return FP8 if t.element_size() == 1 else _DTYPE[t.dtype]
+
+
+def layernorm(x, gamma, beta, out, eps=1e-5, out_inv_scale=0.0):
+    """out[rows, cols] = LayerNorm(x[rows, cols]); x f32; out f32 (may alias x), bf16, or e4m3 bytes of the result
+    times `out_inv_scale`."""
     _dev(x, gamma, beta, out)
     assert x.dtype == torch.float32 and x.dim() == 2 and out.shape == x.shape
     assert x.stride(1) == 1 and out.stride(1) == 1
     _check(load_library().dfd_layernorm(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(out), out.stride(0),
-                                        _DTYPE[out.dtype], x.shape[0], x.shape[1], eps, _stream()), "dfd_layernorm")
+                                        _out_dtype(out), x.shape[0], x.shape[1], eps, float(out_inv_scale), _stream()), "dfd_layernorm")
     return out
 
 
-def add_layernorm(x, delta, gamma, beta, out, eps=1e-5, delta2=None, store_x=True):
-    """v = (x + delta) [+ delta2] (x f32, deltas f32 / bf16); out = LayerNorm(v) in f32 or bf16; x <- v when `store_x`."""
+def add_layernorm(x, delta, gamma, beta, out, eps=1e-5, delta2=None, store_x=True, out_inv_scale=0.0):
+    """v = (x + delta) [+ delta2] (x f32, deltas f32 / bf16); out = LayerNorm(v) in f32, bf16 or e4m3 (times
+    `out_inv_scale`); x <- v when `store_x`."""
     _dev(x, delta, gamma, beta, out, delta2)
     assert x.dtype == torch.float32 and x.dim() == 2 and out.shape == x.shape and delta.shape == x.shape
     assert x.stride(1) == 1 and out.stride(1) == 1 and delta.stride(1) == 1
     assert delta2 is None or (delta2.dtype == delta.dtype and delta2.shape == x.shape and delta2.stride() == delta.stride())
     _check(load_library().dfd_add_layernorm(_ptr(x), x.stride(0), _ptr(delta), _ptr(delta2), delta.stride(0), _DTYPE[delta.dtype],
-                                            int(bool(store_x)), _ptr(gamma), _ptr(beta), _ptr(out), out.stride(0), _DTYPE[out.dtype],
-                                            x.shape[0], x.shape[1], eps, _stream()), "dfd_add_layernorm")
+                                            int(bool(store_x)), _ptr(gamma), _ptr(beta), _ptr(out), out.stride(0), _out_dtype(out),
+                                            x.shape[0], x.shape[1], eps, float(out_inv_scale), _stream()), "dfd_add_layernorm")
     return out
 
 
@@ -257,10 +266,6 @@ def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_ex
         e1.record()
         _profile["events"].append((e0, e1, 2.0 * M * N * K))
     return c
-
-
-FP8 = 2
-FP8_MAX = 448.0  # largest finite e4m3 value
 
 
 def gemm_fp8(a, w, c, col_scale, bias=None, epilogue=EPI_BIAS, m=None, out_inv_scale=0.0, pos=None, k_export=None, v_export=None,

@@ -9,11 +9,34 @@
 //   (clip/model.py:264, :277) is a plain A·Wᵀ GEMM with W = conv1.weight.view(D, 3*p*p).
 #include "common.hpp"
 
+// e4m3 output (the A operand of an fp8 GEMM, dfd_gemm_fp8): stored value = e4m3(y * inv_scale), saturated at +-448
+struct fp8_t {
+  unsigned char v;
+};
+
+template <typename OutT>
+__device__ __forceinline__ void store_row4(OutT* p, f32x4 o, float inv_scale) {
+  if constexpr (sizeof(OutT) == 4) {
+    *reinterpret_cast<f32x4*>(p) = o;
+  } else if constexpr (sizeof(OutT) == 2) {
+    bf16x4 ob;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)o[j];
+    *reinterpret_cast<bf16x4*>(p) = ob;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = __builtin_fminf(__builtin_fmaxf(o[j] * inv_scale, -448.0f), 448.0f);
+    unsigned pk = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0u, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], pk, true);
+    *reinterpret_cast<unsigned*>(p) = pk;
+  }
+}
+
 template <typename OutT, int SLABS>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, int64_t ldx,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, OutT* __restrict__ y,
-                                                             int64_t ldy, int64_t rows, int cols, float eps) {
+                                                             int64_t ldy, int64_t rows, int cols, float eps, float inv_scale) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -54,27 +77,20 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
       f32x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
-      if constexpr (sizeof(OutT) == 4) {
-        *reinterpret_cast<f32x4*>(yr + c) = o;
-      } else {
-        bf16x4 ob;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)o[j];
-        *reinterpret_cast<bf16x4*>(yr + c) = ob;
-      }
+      store_row4(yr + c, o, inv_scale);
     }
   }
 }
 
 template <typename OutT>
 static int launch_ln(const float* x, int64_t ldx, const float* g, const float* b, void* y, int64_t ldy, int64_t rows,
-                     int cols, float eps, hipStream_t st) {
+                     int cols, float eps, float inv_scale, hipStream_t st) {
   const int slabs = (cols + 255) / 256;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   OutT* yo = static_cast<OutT*>(y);
 #define LN_CASE(S)                                                                                     \
   case S:                                                                                              \
-    hipLaunchKernelGGL((layernorm_rows_kernel<OutT, S>), grid, block, 0, st, x, ldx, g, b, yo, ldy, rows, cols, eps); \
+    hipLaunchKernelGGL((layernorm_rows_kernel<OutT, S>), grid, block, 0, st, x, ldx, g, b, yo, ldy, rows, cols, eps, inv_scale); \
     break;
   switch (slabs) {
     LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
@@ -89,16 +105,17 @@ static int launch_ln(const float* x, int64_t ldx, const float* g, const float* b
 }
 
 extern "C" int dfd_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
-                             int y_dtype, int64_t rows, int cols, float eps, void* stream) {
+                             int y_dtype, int64_t rows, int cols, float eps, float y_inv_scale, void* stream) {
   DFD_REQUIRE(x && gamma && beta && y, "dfd_layernorm: null pointer");
   DFD_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= 4096, "dfd_layernorm: cols=%d must be a multiple of 4, <= 4096", cols);
   DFD_REQUIRE(ldx >= cols && ldy >= cols && ldx % 4 == 0 && ldy % 4 == 0, "dfd_layernorm: bad leading dimension (ldx=%lld ldy=%lld)", (long long)ldx, (long long)ldy);
-  DFD_REQUIRE(dfd_aligned16(x) && dfd_aligned16(gamma) && dfd_aligned16(beta) && ((uintptr_t)y & 7) == 0, "dfd_layernorm: pointers must be 16-byte aligned");
-  DFD_REQUIRE(y_dtype == DFD_F32 || y_dtype == DFD_BF16, "dfd_layernorm: y_dtype=%d", y_dtype);
+  DFD_REQUIRE(dfd_aligned16(x) && dfd_aligned16(gamma) && dfd_aligned16(beta) && ((uintptr_t)y & (y_dtype == DFD_FP8 ? 3 : 7)) == 0, "dfd_layernorm: pointers must be 16-byte aligned");
+  DFD_REQUIRE(y_dtype == DFD_F32 || y_dtype == DFD_BF16 || (y_dtype == DFD_FP8 && y_inv_scale > 0.f), "dfd_layernorm: y_dtype=%d (fp8 needs y_inv_scale > 0)", y_dtype);
   if (rows == 0) return DFD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (y_dtype == DFD_F32) return launch_ln<float>(x, ldx, gamma, beta, y, ldy, rows, cols, eps, st);
-  return launch_ln<bf16_t>(x, ldx, gamma, beta, y, ldy, rows, cols, eps, st);
+  if (y_dtype == DFD_F32) return launch_ln<float>(x, ldx, gamma, beta, y, ldy, rows, cols, eps, 1.f, st);
+  if (y_dtype == DFD_FP8) return launch_ln<fp8_t>(x, ldx, gamma, beta, y, ldy, rows, cols, eps, y_inv_scale, st);
+  return launch_ln<bf16_t>(x, ldx, gamma, beta, y, ldy, rows, cols, eps, 1.f, st);
 }
 
 // ---- residual add + LayerNorm ----------------------------------------------------------------
@@ -114,7 +131,7 @@ __global__ __launch_bounds__(256) void add_layernorm_rows_kernel(float* __restri
                                                                  const DeltaT* __restrict__ delta2, int store_x,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, OutT* __restrict__ y,
-                                                                 int64_t ldy, int64_t rows, int cols, float eps) {
+                                                                 int64_t ldy, int64_t rows, int cols, float eps, float inv_scale) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -170,21 +187,14 @@ __global__ __launch_bounds__(256) void add_layernorm_rows_kernel(float* __restri
       f32x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
-      if constexpr (sizeof(OutT) == 4) {
-        *reinterpret_cast<f32x4*>(yr + c) = o;
-      } else {
-        bf16x4 ob;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)o[j];
-        *reinterpret_cast<bf16x4*>(yr + c) = ob;
-      }
+      store_row4(yr + c, o, inv_scale);
     }
   }
 }
 
 template <typename DeltaT, typename OutT>
 static int launch_add_ln(float* x, int64_t ldx, const void* delta, int64_t ldd, const void* delta2, int store_x, const float* g,
-                         const float* b, void* y, int64_t ldy, int64_t rows, int cols, float eps, hipStream_t st) {
+                         const float* b, void* y, int64_t ldy, int64_t rows, int cols, float eps, float inv_scale, hipStream_t st) {
   const int slabs = (cols + 255) / 256;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   const DeltaT* dd = static_cast<const DeltaT*>(delta);
@@ -193,7 +203,7 @@ static int launch_add_ln(float* x, int64_t ldx, const void* delta, int64_t ldd, 
 #define ALN_CASE(S)                                                                                                   \
   case S:                                                                                                             \
     hipLaunchKernelGGL((add_layernorm_rows_kernel<DeltaT, OutT, S>), grid, block, 0, st, x, ldx, dd, ldd, dd2, store_x, g, b,  \
-                       yo, ldy, rows, cols, eps);                                                                     \
+                       yo, ldy, rows, cols, eps, inv_scale);                                                          \
     break;
   switch (slabs) {
     ALN_CASE(1) ALN_CASE(2) ALN_CASE(3) ALN_CASE(4) ALN_CASE(5) ALN_CASE(6) ALN_CASE(7) ALN_CASE(8)
@@ -208,25 +218,27 @@ static int launch_add_ln(float* x, int64_t ldx, const void* delta, int64_t ldd, 
 
 extern "C" int dfd_add_layernorm(float* x, int64_t ldx, const void* delta, const void* delta2, int64_t ldd, int delta_dtype,
                                  int store_x, const float* gamma, const float* beta, void* y, int64_t ldy, int y_dtype,
-                                 int64_t rows, int cols, float eps, void* stream) {
+                                 int64_t rows, int cols, float eps, float y_inv_scale, void* stream) {
   DFD_REQUIRE(x && delta && gamma && beta && y, "dfd_add_layernorm: null pointer");
   DFD_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "dfd_add_layernorm: cols=%d must be a multiple of 4, <= 2048", cols);
   DFD_REQUIRE(ldx >= cols && ldd >= cols && ldy >= cols && ldx % 4 == 0 && ldd % 4 == 0 && ldy % 4 == 0,
               "dfd_add_layernorm: bad leading dimension (ldx=%lld ldd=%lld ldy=%lld)", (long long)ldx, (long long)ldd, (long long)ldy);
-  DFD_REQUIRE(dfd_aligned16(x) && dfd_aligned16(gamma) && dfd_aligned16(beta) && ((uintptr_t)y & 7) == 0 && ((uintptr_t)delta & 7) == 0,
-              "dfd_add_layernorm: pointers must be 16-byte aligned (8 for bf16 operands)");
-  DFD_REQUIRE((delta_dtype == DFD_F32 || delta_dtype == DFD_BF16) && (y_dtype == DFD_F32 || y_dtype == DFD_BF16),
-              "dfd_add_layernorm: delta_dtype=%d y_dtype=%d", delta_dtype, y_dtype);
+  DFD_REQUIRE(dfd_aligned16(x) && dfd_aligned16(gamma) && dfd_aligned16(beta) && ((uintptr_t)y & (y_dtype == DFD_FP8 ? 3 : 7)) == 0 && ((uintptr_t)delta & 7) == 0,
+              "dfd_add_layernorm: pointers must be 16-byte aligned (8 for bf16, 4 for fp8 operands)");
+  DFD_REQUIRE((delta_dtype == DFD_F32 || delta_dtype == DFD_BF16) && (y_dtype == DFD_F32 || y_dtype == DFD_BF16 || (y_dtype == DFD_FP8 && y_inv_scale > 0.f)),
+              "dfd_add_layernorm: delta_dtype=%d y_dtype=%d (fp8 needs y_inv_scale > 0)", delta_dtype, y_dtype);
   DFD_REQUIRE(static_cast<const void*>(x) != y && delta != y && delta2 != y, "dfd_add_layernorm: y must not alias x or a delta");
   DFD_REQUIRE(!delta2 || ((uintptr_t)delta2 & 7) == 0, "dfd_add_layernorm: delta2 must be 8-byte aligned");
   if (rows == 0) return DFD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (delta_dtype == DFD_F32) {
-    if (y_dtype == DFD_F32) return launch_add_ln<float, float>(x, ldx, delta, ldd, delta2, store_x, gamma, beta, y, ldy, rows, cols, eps, st);
-    return launch_add_ln<float, bf16_t>(x, ldx, delta, ldd, delta2, store_x, gamma, beta, y, ldy, rows, cols, eps, st);
+    if (y_dtype == DFD_F32) return launch_add_ln<float, float>(x, ldx, delta, ldd, delta2, store_x, gamma, beta, y, ldy, rows, cols, eps, 1.f, st);
+    if (y_dtype == DFD_FP8) return launch_add_ln<float, fp8_t>(x, ldx, delta, ldd, delta2, store_x, gamma, beta, y, ldy, rows, cols, eps, y_inv_scale, st);
+    return launch_add_ln<float, bf16_t>(x, ldx, delta, ldd, delta2, store_x, gamma, beta, y, ldy, rows, cols, eps, 1.f, st);
   }
-  if (y_dtype == DFD_F32) return launch_add_ln<bf16_t, float>(x, ldx, delta, ldd, delta2, store_x, gamma, beta, y, ldy, rows, cols, eps, st);
-  return launch_add_ln<bf16_t, bf16_t>(x, ldx, delta, ldd, delta2, store_x, gamma, beta, y, ldy, rows, cols, eps, st);
+  if (y_dtype == DFD_F32) return launch_add_ln<bf16_t, float>(x, ldx, delta, ldd, delta2, store_x, gamma, beta, y, ldy, rows, cols, eps, 1.f, st);
+  if (y_dtype == DFD_FP8) return launch_add_ln<bf16_t, fp8_t>(x, ldx, delta, ldd, delta2, store_x, gamma, beta, y, ldy, rows, cols, eps, y_inv_scale, st);
+  return launch_add_ln<bf16_t, bf16_t>(x, ldx, delta, ldd, delta2, store_x, gamma, beta, y, ldy, rows, cols, eps, 1.f, st);
 }
 
 // ---- patchify -----------------------------------------------------------------------------

@@ -6,10 +6,11 @@ inference loops (`src/trainer.py:147-151`, `src/evaluator.py:80-83`, `inference.
 run unchanged on top of it.  The frozen encoder and the decoder execute in
 libdfdclip_hip.so; PyTorch supplies device memory, streams and the tiny per-sample loss.
 
-    Detector(config, num_frames, accelerator, precision="bf16" | "fp32")
+    Detector(config, num_frames, accelerator, precision="bf16" | "fp32" | "fp8")
 
 `precision` is the only addition to the reference signature: "fp32" is the parity path
-(logits within 1e-3 of the reference's fp32 CPU result), "bf16" the throughput path.
+(logits within 1e-3 of the reference's fp32 CPU result), "bf16" the throughput path, "fp8" the bf16 path
+with the encoder's large projections on e4m3 matrix-core operands (BASELINE configs[4]; `calibrate_fp8`).
 """
 import contextlib
 import logging
@@ -266,6 +267,12 @@ class Detector(RuntimeStateMixin, nn.Module):
             if self.adapter is not None and self.adapter.struct.endswith("nln"):
                 raise NotImplementedError("patch_mask with the nln adapter: its LayerNorm is sized for all patches "
                                           "(the reference fails on this combination too)")
+
+    @torch.no_grad()
+    def calibrate_fp8(self, x, margin=1.0):
+        """fp8 path: fix the encoder's static activation scales from representative clips x [B,T,3,R,R] (or frames
+        [N,3,R,R]); see `VisionTransformer.calibrate_fp8`.  Without it the first forward calibrates on its own batch."""
+        return self.encoder.calibrate_fp8(x.flatten(0, 1) if x.dim() == 5 else x, margin=margin)
 
     def seed_dropout(self, seed):
         """Fix the dropout stream: the same seed (and the same number of training forwards since) gives the

@@ -7,10 +7,17 @@ same `forward(x, with_out, with_q)` result — a list with one dict per block ho
 `k`, `v` `[N, tokens, heads, 64]` (bias included, un-scaled, CLS row kept).  `ln_post` and
 `proj` exist as parameters and, as in the reference, are never applied.
 
-All arithmetic runs in libdfdclip_hip.so.  Two precisions:
+All arithmetic runs in libdfdclip_hip.so.  Three precisions:
   * "fp32": f32 operands on the exact-f32 matrix cores — the 1e-3 parity path;
   * "bf16": bf16 GEMM/attention operands, f32 accumulation, f32 residual stream, f32
-    LayerNorm/softmax statistics — the throughput path.
+    LayerNorm/softmax statistics — the throughput path;
+  * "fp8" (BASELINE.json configs[4]): the bf16 path with the three large projections of every block — q|k|v,
+    c_fc, c_proj, 92 % of the encoder's FLOPs — on OCP e4m3 operands (`dfd_gemm_fp8`, block-scaled matrix
+    cores at twice the bf16 rate).  Weights: one scale per output row (amax / 448), quantised once.
+    Activations: LayerNorm writes its output, and c_fc its QuickGELU output, directly as e4m3 with ONE static
+    scale per tensor and layer, taken from a calibration batch (`calibrate_fp8`; the first fp8 forward
+    calibrates on its own input otherwise): amax / 448, values beyond it saturate.  Accumulation, bias,
+    residual stream, attention, out_proj and the K/V export stay as in the bf16 path.
 
 HBM layout for a batch of N frames (M = N*tokens rows, D = width), all row-major:
   x    [M, D]   f32   residual stream (updated in place by the residual epilogues)
@@ -92,12 +99,12 @@ class Transformer(_Holder):
 
 
 class VisionTransformer(RuntimeStateMixin, nn.Module):
-    _RUNTIME_STATE = {"_prepared": None, "_ws": {}, "_side_streams": []}
+    _RUNTIME_STATE = {"_prepared": None, "_ws": {}, "_side_streams": [], "_calib": None}
 
     def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim, precision="bf16"):
         super().__init__()
         assert width % heads == 0 and width // heads == 64, "kernels are built for 64-wide heads"
-        assert precision in ("fp32", "bf16")
+        assert precision in ("fp32", "bf16", "fp8")
         self.input_resolution = input_resolution
         self.output_dim = output_dim
         self.width = width
@@ -128,7 +135,9 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         self.antialias = True
         # bf16 path: residual branches are stored as bf16 deltas and added inside the next LayerNorm
         # (see `_residual`); the fp32 parity path keeps the read-modify-write epilogue
-        self.deferred_residual = precision == "bf16"
+        self.deferred_residual = precision in ("bf16", "fp8")
+        self._fp8 = None  # fp8 path: per-layer activation scales and column-scale vectors (calibrate_fp8)
+        self._calib = None
         # which GEMM outputs are stored non-temporally (capi.gemm stream_out): they are written once and read back only
         # after other traffic has flushed the caches anyway, and keeping them out of L2 leaves the operand panels there
         self.stream_out = {"qkv": True, "out": True, "fc": True, "proj": True}
@@ -145,19 +154,60 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
     def act_dtype(self):
         return torch.float32 if self.precision == "fp32" else torch.bfloat16
 
+    # ---- fp8 activation scales ------------------------------------------------------------------
+    def _ensure_fp8(self, frames):
+        if self.precision == "fp8" and self._fp8 is None and getattr(self, "_calib", None) is None:
+            import logging
+            logging.warning("fp8 encoder: no calibration yet, taking the activation scales from this batch "
+                            "(call encoder.calibrate_fp8(frames) with representative frames to fix them beforehand)")
+            self.calibrate_fp8(frames[:min(frames.shape[0], 64)])
+
+    @torch.no_grad()
+    def calibrate_fp8(self, x, margin=1.0):
+        """Static activation scales of the fp8 path from one batch of frames [N,3,R,R]: runs the bf16 arithmetic
+        once, records the largest magnitude of each quantised tensor (ln_1 output, ln_2 output, QuickGELU(c_fc)
+        output) per layer, and fixes scale = margin * amax / 448.  Later batches saturate beyond it."""
+        assert self.precision == "fp8"
+        p = self._prepare()
+        frames = self._as_frames(x)
+        n = frames.shape[0]
+        M = n * self.tokens
+        rec = []
+        self._calib = rec
+        try:
+            ws = self._workspace(n, 1, slot=99)
+            self._embed(frames, ws, p)
+            for bp in p["blocks"]:
+                self._block(ws, bp, ws["qkv"][0], M, n)
+        finally:
+            self._calib = None
+            self._ws.pop((n, self.precision, 1, 99), None)
+        amax = torch.stack(rec).view(len(p["blocks"]), 3).float().cpu()  # one host sync, at calibration time only
+        scales = (amax * margin / capi.FP8_MAX).clamp_min(1e-12)
+        layers = []
+        for l, bp in enumerate(p["blocks"]):
+            s1, s2, su = (float(v) for v in scales[l])
+            layers.append(dict(h1_inv=1.0 / s1, h2_inv=1.0 / s2, u_inv=1.0 / su, cs_qkv=(bp["s_qkv"] * s1).contiguous(),
+                               cs_fc=(bp["s_fc"] * s2).contiguous(), cs_proj=(bp["s_proj"] * su).contiguous()))
+        self._fp8 = layers
+        return scales
+
     def invalidate(self):
         """Call after changing parameters in place (load_state_dict and .to() do it themselves)."""
         self._prepared = None
+        self._fp8 = None
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._prepared = None
+        self._fp8 = None
         self._ws = {}
         return out
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
         self._prepared = None
+        self._fp8 = None
         return out
 
     def _prepare(self):
@@ -174,8 +224,20 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         p = dict(kpad=kpad, w_patch=wp.to(act).contiguous(), cls=f32(self.class_embedding),
                  pos=f32(self.positional_embedding), ln_pre=(f32(self.ln_pre.weight), f32(self.ln_pre.bias)), blocks=[])
+        def q8(w):
+            """[N, K] weight -> (e4m3 bytes of w / scale_row, scale_row f32 [N]); scale_row = amax_row / 448."""
+            w = w.detach().to(torch.float32)
+            sc = (w.abs().amax(dim=1) / capi.FP8_MAX).clamp_min(1e-12)
+            return (w / sc[:, None]).to(torch.float8_e4m3fn).view(torch.uint8).contiguous(), sc.contiguous()
+
         for blk in self.transformer.resblocks:
-            p["blocks"].append(dict(
+            if self.precision == "fp8":
+                f8 = dict(zip(("w_qkv8", "s_qkv"), q8(blk.attn.in_proj_weight)))
+                f8.update(zip(("w_fc8", "s_fc"), q8(blk.mlp.c_fc.weight)))
+                f8.update(zip(("w_proj8", "s_proj"), q8(blk.mlp.c_proj.weight)))
+            else:
+                f8 = {}
+            p["blocks"].append(dict(f8, idx=len(p["blocks"]), 
                 ln1=(f32(blk.ln_1.weight), f32(blk.ln_1.bias)), ln2=(f32(blk.ln_2.weight), f32(blk.ln_2.bias)),
                 w_qkv=blk.attn.in_proj_weight.detach().to(act).contiguous(), b_qkv=f32(blk.attn.in_proj_bias),
                 w_out=blk.attn.out_proj.weight.detach().to(act).contiguous(), b_out=f32(blk.attn.out_proj.bias),
@@ -204,6 +266,9 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
                 delta=torch.zeros(Mp, D, device=dev, dtype=act) if self.deferred_residual else None,
                 delta2=torch.zeros(Mp, D, device=dev, dtype=act) if self.deferred_residual else None, pending=0,
                 qkv=[torch.zeros(Mp, 3 * D, device=dev, dtype=act) for _ in range(keep_layers)])
+            if self.precision == "fp8":
+                ws["h8"] = torch.zeros(Mp, D, device=dev, dtype=torch.uint8)
+                ws["u8"] = torch.zeros(Mp, 4 * D, device=dev, dtype=torch.uint8)
             if len(self._ws) > 6:
                 self._ws.clear()
             self._ws[key] = ws
@@ -236,20 +301,22 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         ws["pending"] = 0
         capi.layernorm(ws["x"][:M], p["ln_pre"][0], p["ln_pre"][1], ws["x"][:M])
 
-    def _ln(self, ws, gb, M, store=True):
+    def _ln(self, ws, gb, M, store=True, q=None):
         """h = LayerNorm(x).  On the bf16 path the residual branches that have not been added yet
         (`ws["pending"]` of them: out_proj wrote `ws["delta"]`, c_proj `ws["delta2"]`) are folded in first
         inside the same pass over the rows (dfd_add_layernorm).  ln_2 (`store=False`) normalises
         x + delta without storing it; the next ln_1 adds both deltas and stores x once per block."""
-        x, h = ws["x"], ws["h"]
+        x = ws["x"]
+        h, inv = (ws["h8"], q) if q is not None else (ws["h"], 0.0)  # q: e4m3 output with this inverse scale (fp8 path)
         pend = ws.get("pending", 0)
         if pend == 0:
-            capi.layernorm(x[:M], gb[0], gb[1], h[:M])
+            capi.layernorm(x[:M], gb[0], gb[1], h[:M], out_inv_scale=inv)
         elif not store:
             assert pend == 1
-            capi.add_layernorm(x[:M], ws["delta"][:M], gb[0], gb[1], h[:M], store_x=False)
+            capi.add_layernorm(x[:M], ws["delta"][:M], gb[0], gb[1], h[:M], store_x=False, out_inv_scale=inv)
         else:
-            capi.add_layernorm(x[:M], ws["delta"][:M], gb[0], gb[1], h[:M], delta2=ws["delta2"][:M] if pend == 2 else None)
+            capi.add_layernorm(x[:M], ws["delta"][:M], gb[0], gb[1], h[:M], delta2=ws["delta2"][:M] if pend == 2 else None,
+                               out_inv_scale=inv)
             ws["pending"] = 0
 
     def _residual(self, ws, a, w, b, M):
@@ -277,29 +344,44 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         """One residual attention block (model.py:220-226).  `export` = (k_out, v_out, tpos, T)
         makes the QKV epilogue also write the decoder operands; `kv_only` stops after the
         projection (nothing after it can reach an exported tensor)."""
-        h = ws["h"]
-        self._ln(ws, bp["ln1"], M)
-        if export is not None and kv_only:
-            # last tapped layer: only its K and V are read, so the query third of the projection is skipped too
-            D = self.width
-            capi.gemm(h, bp["w_qkv"][D:], qkv[:, D:], bp["b_qkv"][D:], capi.EPI_QKV_EXPORT, m=M, pos=export[2],
-                      k_export=export[0], v_export=export[1], tokens=self.tokens, frames_per_clip=export[3], qkv_first=1,
-                      stream_out=self.stream_out["qkv"], spare_cus=self.spare_cus)
-        elif export is not None:
-            capi.gemm(h, bp["w_qkv"], qkv, bp["b_qkv"], capi.EPI_QKV_EXPORT, m=M, pos=export[2], k_export=export[0],
-                      v_export=export[1], tokens=self.tokens, frames_per_clip=export[3], stream_out=self.stream_out["qkv"],
-                      spare_cus=self.spare_cus)
+        calib = getattr(self, "_calib", None)
+        f8 = self._fp8[bp["idx"]] if self.precision == "fp8" and calib is None else None
+        so, sp = self.stream_out, self.spare_cus
+        D = self.width
+        # q | k | v projection (+ K/V export); the last tapped layer computes only the K and V thirds
+        first = 1 if (export is not None and kv_only) else 0
+        rows = slice(D, None) if first else slice(None)
+        kw = dict(m=M, tokens=self.tokens, qkv_first=first, stream_out=so["qkv"], spare_cus=sp)
+        if export is not None:
+            kw.update(pos=export[2], k_export=export[0], v_export=export[1], frames_per_clip=export[3])
+        if f8 is not None:
+            self._ln(ws, bp["ln1"], M, q=f8["h1_inv"])
+            capi.gemm_fp8(ws["h8"], bp["w_qkv8"][rows], qkv[:, rows], f8["cs_qkv"][rows], bp["b_qkv"][rows], capi.EPI_QKV_EXPORT, **kw)
         else:
-            capi.gemm(h, bp["w_qkv"], qkv, bp["b_qkv"], capi.EPI_QKV_EXPORT, m=M, tokens=self.tokens, stream_out=self.stream_out["qkv"],
-                      spare_cus=self.spare_cus)
+            self._ln(ws, bp["ln1"], M)
+            if calib is not None:
+                calib.append(ws["h"][:M].abs().max())
+            capi.gemm(ws["h"], bp["w_qkv"][rows], qkv[:, rows], bp["b_qkv"][rows], capi.EPI_QKV_EXPORT, **kw)
         if kv_only:
             return
         capi.attention_fwd(qkv, ws["mix"], n, self.tokens, self.heads)
         self._residual(ws, ws["mix"], bp["w_out"], bp["b_out"], M)
-        self._ln(ws, bp["ln2"], M, store=False)
-        capi.gemm(h, bp["w_fc"], ws["u"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M, stream_out=self.stream_out["fc"],
-                  spare_cus=self.spare_cus)
-        self._residual(ws, ws["u"], bp["w_proj"], bp["b_proj"], M)
+        if f8 is not None:
+            self._ln(ws, bp["ln2"], M, store=False, q=f8["h2_inv"])
+            capi.gemm_fp8(ws["h8"], bp["w_fc8"], ws["u8"], f8["cs_fc"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M,
+                          out_inv_scale=f8["u_inv"], stream_out=so["fc"], spare_cus=sp)
+            pend = ws.get("pending", 0)  # c_proj: the second deferred residual of the block (see `_residual`)
+            capi.gemm_fp8(ws["u8"], bp["w_proj8"], ws["delta2" if pend else "delta"], f8["cs_proj"], bp["b_proj"], capi.EPI_BIAS, m=M,
+                          stream_out=so["proj"], spare_cus=sp)
+            ws["pending"] = pend + 1
+        else:
+            self._ln(ws, bp["ln2"], M, store=False)
+            if calib is not None:
+                calib.append(ws["h"][:M].abs().max())
+            capi.gemm(ws["h"], bp["w_fc"], ws["u"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M, stream_out=so["fc"], spare_cus=sp)
+            if calib is not None:
+                calib.append(ws["u"][:M].abs().max())
+            self._residual(ws, ws["u"], bp["w_proj"], bp["b_proj"], M)
 
     @torch.no_grad()
     def forward(self, x, with_out=False, with_q=False):
@@ -309,6 +391,7 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         p = self._prepare()
         frames = self._as_frames(x)
         n = frames.shape[0]
+        self._ensure_fp8(frames)
         D, H, tok = self.width, self.heads, self.tokens
         M = n * tok
         ws = self._workspace(n, self.layers)
@@ -342,6 +425,7 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         frames = self._as_frames(x)
         n = frames.shape[0]
         assert n % num_frames == 0
+        self._ensure_fp8(frames)
         D, tok = self.width, self.tokens
         P = tok - 1
         L = len(layer_indices)

@@ -98,7 +98,9 @@ int dfd_device_check(void);                /* DFD_OK iff device 0.. current is g
  * y in y_dtype (row stride ldy); y may alias x when y_dtype == DFD_F32.
  * cols % 4 == 0, cols <= 4096. */
 int dfd_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
-                  int y_dtype, int64_t rows, int cols, float eps, void* stream);
+                  int y_dtype, int64_t rows, int cols, float eps, float y_inv_scale, void* stream);
+/* y_dtype DFD_FP8 (both LayerNorm entry points): y = e4m3(LayerNorm(..) * y_inv_scale), saturated at +-448 — the A
+ * operand of dfd_gemm_fp8; y_inv_scale is ignored for the other output types. */
 
 /* Residual add fused with the LayerNorm that follows it: v = (x[rows, cols] + delta) [+ delta2], deltas in
  * delta_dtype with one leading dimension ldd; y = LayerNorm(v) as dfd_layernorm; x (f32) is overwritten with v
@@ -108,7 +110,7 @@ int dfd_layernorm(const float* x, int64_t ldx, const float* gamma, const float* 
  * stores x once per block.  delta2 may be NULL.  y must not alias x or a delta.  cols % 4 == 0, cols <= 2048. */
 int dfd_add_layernorm(float* x, int64_t ldx, const void* delta, const void* delta2, int64_t ldd, int delta_dtype,
                       int store_x, const float* gamma, const float* beta, void* y, int64_t ldy, int y_dtype, int64_t rows,
-                      int cols, float eps, void* stream);
+                      int cols, float eps, float y_inv_scale, void* stream);
 
 /* Frames [n_frames, 3, res, res] (f32) -> patch rows [n_frames*P, kpad] in out_dtype, column
  * k = c*patch*patch + i*patch + j (the flatten order of conv1.weight [D,3,patch,patch]), columns

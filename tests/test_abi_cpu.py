@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_invalid_arguments_are_reported_not_launched(lib):
     # null pointers / bad shapes are rejected on the host before any launch (no GPU needed)
-    rc = lib.dfd_layernorm(None, 0, None, None, None, 0, 0, 1, 8, 1e-5, None)
+    rc = lib.dfd_layernorm(None, 0, None, None, None, 0, 0, 1, 8, 1e-5, 0.0, None)
     assert rc == -1 and b"null pointer" in lib.dfd_last_error()
     rc = lib.dfd_gemm(1 << 12, 48, 1 << 12, 48, capi.BF16, 1 << 12, 8, capi.BF16, None, capi.EPI_BIAS, None, 4, 8, 48, None)
     assert rc == -1 and b"multiple of 32" in lib.dfd_last_error()
