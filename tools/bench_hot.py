@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One pass over the encoder's hot kernels at the B16xT30 shapes (for PMC collection under rocprofv3):
-the four GEMMs, both add-LayerNorm forms, plain LayerNorm and the attention kernel, a few launches each."""
+the four GEMMs (as the encoder launches them: persistent kernel, streaming output stores, K/V export on the
+q|k|v projection), both add-LayerNorm forms and the attention kernel, a few launches each."""
 import os
 import sys
 
@@ -28,13 +29,16 @@ bq, bo, bf_, bp = (torch.randn(n, device=dev) * 0.1 for n in (3 * D, D, 4 * D, D
 qkv = torch.empty(M, 3 * D, device=dev, dtype=bf)
 mix = torch.empty(M, D, device=dev, dtype=bf)
 hh = torch.empty(M, D, device=dev, dtype=bf)
+tpos = torch.randn(30, D, device=dev)
+ke = torch.empty(frames * (tok - 1), D, device=dev, dtype=bf)
+ve = torch.empty_like(ke)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
-    capi.gemm(h, wq, qkv, bq, capi.EPI_QKV_EXPORT, tokens=tok)
+    capi.gemm(h, wq, qkv, bq, capi.EPI_QKV_EXPORT, tokens=tok, pos=tpos, k_export=ke, v_export=ve, frames_per_clip=30, stream_out=True)
     capi.attention_fwd(qkv, mix, frames, tok, H)
-    capi.gemm(mix, wo, d1, bo, capi.EPI_BIAS)
+    capi.gemm(mix, wo, d1, bo, capi.EPI_BIAS, stream_out=True)
     capi.add_layernorm(x, d1, g, b, hh, store_x=False)
-    capi.gemm(hh, wf, u, bf_, capi.EPI_BIAS_QUICKGELU)
-    capi.gemm(u, wp, d2, bp, capi.EPI_BIAS)
+    capi.gemm(hh, wf, u, bf_, capi.EPI_BIAS_QUICKGELU, stream_out=True)
+    capi.gemm(u, wp, d2, bp, capi.EPI_BIAS, stream_out=True)
     capi.add_layernorm(x, d1, g, b, hh, delta2=d2)
     x.mul_(0.5)  # keep the stream bounded over the iterations
 torch.cuda.synchronize()
