@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--ingest-size", type=int, nargs=2, default=None, metavar=("H", "W"),
                     help="with --ingest u8: source frame size (default = the model's resolution, i.e. no resize)")
     ap.add_argument("--spare-cus", type=int, default=-1, help="CUs the encoder GEMMs leave to the decoder stream in pipelined training (-1 = package default)")
+    ap.add_argument("--spare-layers", type=int, default=-1, help="encoder blocks at the start of a pass that leave the spare CUs free (-1 = package default, 0 = all)")
     ap.add_argument("--gemm-stream-out", default=None,
                     help="comma list of encoder GEMM outputs stored non-temporally (qkv,out,fc,proj; 'none'); default = package default")
     ap.add_argument("--adapter", default="none", choices=["none", "nln", "z0", "ln"],
@@ -94,6 +95,8 @@ def build_model(args, device):
         det.encoder.streams = args.streams
     if args.spare_cus >= 0:
         det.pipeline_spare_cus = args.spare_cus
+    if args.spare_layers >= 0:
+        det.pipeline_spare_layers = args.spare_layers
     if args.gemm_stream_out is not None:
         on = set(args.gemm_stream_out.split(",")) - {"none", ""}
         det.encoder.stream_out = {k: k in on for k in det.encoder.stream_out}

@@ -241,6 +241,8 @@ class Detector(RuntimeStateMixin, nn.Module):
         self.pipeline_encoder = False
         self.inputs_ready = False
         self.pipeline_spare_cus = None  # None = one compute unit per shader engine (CUs / 8), see `_encode`
+        self.pipeline_spare_layers = 4  # encoder blocks at the start of a pass that leave those CUs free (0 = all): the
+                                        # previous step's decoder chain is done within about four blocks' time
         self._enc_stream = None
         self._pipe_events = [[], []]
         self._pipe_step = 0
@@ -357,6 +359,7 @@ class Detector(RuntimeStateMixin, nn.Module):
         if spare is None:
             spare = torch.cuda.get_device_properties(x.device).multi_processor_count // 8
         self.encoder.spare_cus = spare if torch.is_grad_enabled() and self.training else 0
+        self.encoder.spare_layers = self.pipeline_spare_layers
         try:
             with torch.cuda.stream(E):
                 kv = self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos, out=out, pos_ready=pos_ready)

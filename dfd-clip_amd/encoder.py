@@ -144,6 +144,7 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         # compute units the persistent GEMMs leave free (capi.gemm spare_cus): set by Detector while it overlaps the
         # decoder's backward / optimizer of the previous step with this encoder pass
         self.spare_cus = 0
+        self.spare_layers = 0  # ... and only in the first `spare_layers` blocks of a pass (0 = all of them)
 
     # ---- derived device-side operands ---------------------------------------------------
     @property
@@ -319,14 +320,15 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
                                out_inv_scale=inv)
             ws["pending"] = 0
 
-    def _residual(self, ws, a, w, b, M):
+    def _residual(self, ws, a, w, b, M, spare_cus=0):
         """x = x + Linear(a) (model.py:222-223).  fp32 path: read-modify-write of x in the GEMM
         epilogue.  bf16 path: the GEMM stores its output as a bf16 delta (plain store epilogue, a
         quarter of the epilogue bytes) and the add is deferred to the LayerNorm that follows."""
         if self.deferred_residual:
             pend = ws.get("pending", 0)
             assert pend < 2
-            capi.gemm(a, w, ws["delta2" if pend else "delta"], b, capi.EPI_BIAS, m=M, stream_out=self.stream_out["proj" if pend else "out"], spare_cus=self.spare_cus)
+            capi.gemm(a, w, ws["delta2" if pend else "delta"], b, capi.EPI_BIAS, m=M, stream_out=self.stream_out["proj" if pend else "out"],
+                      spare_cus=spare_cus)
             ws["pending"] = pend + 1
         else:
             capi.gemm(a, w, ws["x"], b, capi.EPI_BIAS_RESIDUAL, m=M)
@@ -346,7 +348,8 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         projection (nothing after it can reach an exported tensor)."""
         calib = getattr(self, "_calib", None)
         f8 = self._fp8[bp["idx"]] if self.precision == "fp8" and calib is None else None
-        so, sp = self.stream_out, self.spare_cus
+        so = self.stream_out
+        sp = self.spare_cus if (self.spare_layers <= 0 or bp["idx"] < self.spare_layers) else 0
         D = self.width
         # q | k | v projection (+ K/V export); the last tapped layer computes only the K and V thirds
         first = 1 if (export is not None and kv_only) else 0
@@ -365,7 +368,7 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         if kv_only:
             return
         capi.attention_fwd(qkv, ws["mix"], n, self.tokens, self.heads)
-        self._residual(ws, ws["mix"], bp["w_out"], bp["b_out"], M)
+        self._residual(ws, ws["mix"], bp["w_out"], bp["b_out"], M, spare_cus=sp)
         if f8 is not None:
             self._ln(ws, bp["ln2"], M, store=False, q=f8["h2_inv"])
             capi.gemm_fp8(ws["h8"], bp["w_fc8"], ws["u8"], f8["cs_fc"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M,
@@ -381,7 +384,7 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
             capi.gemm(ws["h"], bp["w_fc"], ws["u"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M, stream_out=so["fc"], spare_cus=sp)
             if calib is not None:
                 calib.append(ws["u"][:M].abs().max())
-            self._residual(ws, ws["u"], bp["w_proj"], bp["b_proj"], M)
+            self._residual(ws, ws["u"], bp["w_proj"], bp["b_proj"], M, spare_cus=sp)
 
     @torch.no_grad()
     def forward(self, x, with_out=False, with_q=False):
