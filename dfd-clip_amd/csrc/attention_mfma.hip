@@ -16,7 +16,6 @@
 //     Vt fragment), so P never touches LDS; a lane ends with 4 consecutive output channels of
 //     its query per register group and stores them as 8-byte pieces.
 #include "common.hpp"
-#include <stdlib.h>
 
 #ifndef ATTN_STAMPS
 #define ATTN_STAMPS 0  // diagnostic build: wave 0 of each workgroup writes cycle stamps to `out`-adjacent debug memory
@@ -270,101 +269,235 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const bf16_t* __restr
 #endif
 }
 
-// ---- persistent variant (NB <= 8) --------------------------------------------------------------------
-// One 512-thread workgroup per CU walks (frame, head) items.  K and V of an item go to LDS by LDS-DMA
-// (global_load_lds, no register round trip, swizzle applied on the source address; rows of pad keys come
-// from a 16-byte zero constant), double-buffered: item i+1 is in flight while item i is computed, so
-// the HBM latency that the 4-wave kernel above pays in front of every item (a quarter of its time) is
-// hidden and there is one workgroup barrier per item.  Wave w owns query block w (one wave idles when
-// NB = 7).  V stays row-major [key][64] and its MFMA operand (d rows, 8 keys per lane: two runs of 4
-// keys) is read with the transposing LDS read ds_read_b64_tr_b16 — no transposed 2-byte stores.
-// LDS image of V: 128-byte rows, 16-byte chunk c of key k at position c ^ (((k >> 1) & 1) << 2):
-// the 4 keys x 64 bytes a 32-lane half reads hit 64 distinct banks.
+// ---- persistent variant (tokens <= 208) -----------------------------------------------------------------
+// One 512-thread workgroup per CU walks (frame, head) items; every byte of an item moves as whole 128-byte
+// lines.  K, V and the Q rows of an item go to LDS by LDS-DMA (buffer_load ... lds: no register round trip, the
+// bank swizzle applied on the SOURCE address), double-buffered: item i+1 is in flight while item i is computed,
+// and there is one workgroup barrier per item.  Wave w owns query block w (one wave only stages when NB = 7).
+//   LDS: [K0][V0][K1][V1] images of `tokens` 128-byte rows (no pad rows: the MFMA reads of key rows
+//   tokens .. 32*NB-1 fall into whatever follows — K scores of those keys are overwritten with -inf, their P is
+//   exactly 0 and what V reads there is finite: real bf16 data or the zeros the kernel starts with), then two
+//   4 KB Q images per wave.  The output tile of a wave (32 queries x 64 channels) is transposed through the Q
+//   image it has just consumed and leaves as 16-byte-per-lane, whole-line stores.
+// V stays row-major [key][64] and its MFMA operand (d rows, 8 keys per lane: two runs of 4 keys) is read with the
+// transposing LDS read ds_read_b64_tr_b16.  V image: 16-byte chunk c of key k at position c ^ (((k >> 1) & 1) << 2):
+// the 4 keys x 64 bytes a 32-lane half reads hit 64 distinct banks.  K and Q images: chunk c of row r at
+// c ^ ((r >> 1) & 7).
+// Items are dealt so that the workgroups of one XCD (blockIdx % 8) walk the heads of the same few frames at the
+// same time: their 128-byte pieces of a qkv row are neighbours in memory.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 typedef short short4v __attribute__((ext_vector_type(4)));
-__device__ const uint4 kAttnZero16 = {0u, 0u, 0u, 0u};
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// LDS-DMA by the loader wave, in 1 KB pieces (8 rows): lane (sub = lane >> 3, pos = lane & 7) moves 16-byte chunk
+// pos^swizzle of row 8*piece + sub; the swizzle of the K and Q images, ((row >> 1) & 7), depends on the piece only
+// through its parity.  attn_stage_k / _v issue exactly `np` instructions (every piece has live lanes), _q 4*NB.
+__device__ __forceinline__ void attn_stage_k(__amdgpu_buffer_rsrc_t srd, unsigned char* kimg, uint32_t sbase, uint32_t ldq,
+                                             uint32_t Db, int lane, int np, int tokens) {
+  const int sub = lane >> 3, pos = lane & 7;
+  const uint32_t row0 = (uint32_t)sub * ldq;
+  const uint32_t k_even = row0 + Db + ((pos ^ ((sub >> 1) & 3)) << 4), k_odd = row0 + Db + ((pos ^ (((sub >> 1) & 3) | 4)) << 4);
+  for (int p = 0; p < np; ++p) {
+    if (8 * p + sub < tokens)  // lanes past the image write nothing
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(kimg + p * 1024), 16, ((p & 1) ? k_odd : k_even) + p * 8 * ldq, sbase, 0, 0);
+  }
+}
+__device__ __forceinline__ void attn_stage_v(__amdgpu_buffer_rsrc_t srd, unsigned char* vimg, uint32_t sbase, uint32_t ldq,
+                                             uint32_t Db, int lane, int np, int tokens) {
+  const int sub = lane >> 3, pos = lane & 7;
+  const uint32_t v_any = (uint32_t)sub * ldq + 2 * Db + ((pos ^ (((sub >> 1) & 1) << 2)) << 4);
+  for (int p = 0; p < np; ++p) {
+    if (8 * p + sub < tokens)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(vimg + p * 1024), 16, v_any + p * 8 * ldq, sbase, 0, 0);
+  }
+}
+template <int NB>
+__device__ __forceinline__ void attn_stage_q(__amdgpu_buffer_rsrc_t srd, unsigned char* qimg, uint32_t sbase, uint32_t ldq, int lane,
+                                             int tokens) {
+  const int sub = lane >> 3, pos = lane & 7;
+  const uint32_t q_even = (pos ^ ((sub >> 1) & 3)) << 4, q_odd = (pos ^ (((sub >> 1) & 3) | 4)) << 4;
+#pragma unroll
+  for (int p = 0; p < 4 * NB; ++p) {  // query rows past the frame repeat its last row (never stored)
+    const uint32_t row = (uint32_t)min(8 * p + sub, tokens - 1);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(qimg + p * 1024), 16, row * ldq + ((p & 1) ? q_odd : q_even), sbase, 0, 0);
+  }
+}
+
+// s_waitcnt vmcnt(n) for a run-time n (the loader wave only): at most n of my memory instructions still in flight
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+  switch (n < 0 ? 0 : n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+    case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+    case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
+    case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+    case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+    case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+    case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+    case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+    case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+    case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+    case 41: asm volatile("s_waitcnt vmcnt(41)" ::: "memory"); break;
+    case 42: asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); break;
+    case 43: asm volatile("s_waitcnt vmcnt(43)" ::: "memory"); break;
+    case 44: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+    case 45: asm volatile("s_waitcnt vmcnt(45)" ::: "memory"); break;
+    case 46: asm volatile("s_waitcnt vmcnt(46)" ::: "memory"); break;
+    case 47: asm volatile("s_waitcnt vmcnt(47)" ::: "memory"); break;
+    case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+    case 49: asm volatile("s_waitcnt vmcnt(49)" ::: "memory"); break;
+    case 50: asm volatile("s_waitcnt vmcnt(50)" ::: "memory"); break;
+    case 51: asm volatile("s_waitcnt vmcnt(51)" ::: "memory"); break;
+    case 52: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
+    case 53: asm volatile("s_waitcnt vmcnt(53)" ::: "memory"); break;
+    case 54: asm volatile("s_waitcnt vmcnt(54)" ::: "memory"); break;
+    case 55: asm volatile("s_waitcnt vmcnt(55)" ::: "memory"); break;
+    case 56: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+  }
+}
 
 template <int NB>
-__global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __restrict__ qkv, int64_t ld_qkv,
-                                                                bf16_t* __restrict__ out, int64_t ld_out, int tokens,
-                                                                int heads, int n_items, float scale_log2e) {
-  constexpr int KEYS = NB * 32;
-  constexpr int HALF = KEYS * 128;        // K image, then V image
-  constexpr int BUF = 2 * HALF;
+__global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __restrict__ qkv, uint32_t ldq /* bytes */,
+                                                                bf16_t* __restrict__ out, uint32_t ldo /* bytes */,
+                                                                int tokens, int heads, int n_frames, uint32_t qkv_bytes,
+                                                                uint32_t out_bytes, float scale_log2e) {
+  constexpr int QIMG = 32 * 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  int lane = tid & 63;
+  asm volatile("" : "+v"(lane));  // opaque: per-item addresses are rebuilt from it instead of living in registers
   const int r = lane & 31, h = lane >> 5;
-  const int D = heads * HD;
+  const uint32_t Db = (uint32_t)heads * HD * 2;
   const int ksw = (r >> 1) & 7;
+  const int img = tokens * 128;
+  const int np = (tokens * 8 + 63) >> 6;  // 1 KB pieces per K or V image (the last one partial)
+  const __amdgpu_buffer_rsrc_t srdQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qkv), 0, (int)qkv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)out_bytes, 0x00020000);
+  unsigned char* const qs0 = smem + 4 * img + (wave < NB ? wave : 0) * QIMG;  // my Q image of buffer 0; buffer 1 is NB * QIMG further
 
-  // stage K and V of `item` into buffer `b`: 2*KEYS/8 one-KiB pieces, dealt round-robin to the 8 waves.
-  // The per-lane source offsets do not depend on the item: computed once (-1 = pad key -> zero constant).
-  constexpr int PIECES = KEYS / 8;  // per operand
-  constexpr int MYP = (2 * PIECES + 7) / 8;
-  int64_t soff[MYP];
-#pragma unroll
-  for (int i = 0; i < MYP; ++i) {
-    const int piece = wave + 8 * i;
-    const int isv = piece >= PIECES;
-    const int pp = isv ? piece - PIECES : piece;
-    const int key = pp * 8 + (lane >> 3), pos = lane & 7;
-    const int ch = isv ? (pos ^ (((key >> 1) & 1) << 2)) : (pos ^ ((key >> 1) & 7));
-    soff[i] = (piece < 2 * PIECES && key < tokens) ? (int64_t)key * ld_qkv + (isv ? 2 * D : D) + ch * 8 : -1;
-  }
-  auto stage = [&](int item, int b) {
-    const int frame = item / heads, head = item - frame * heads;
-    const bf16_t* base = qkv + (int64_t)frame * tokens * ld_qkv + head * HD;
-    unsigned char* kb_ = smem + b * BUF;
-#pragma unroll
-    for (int i = 0; i < MYP; ++i) {
-      const int piece = wave + 8 * i;
-      if (piece < 2 * PIECES) {
-        const int isv = piece >= PIECES;
-        const int pp = isv ? piece - PIECES : piece;
-        const void* g = soff[i] >= 0 ? static_cast<const void*>(base + soff[i]) : static_cast<const void*>(&kAttnZero16);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(kb_ + isv * HALF + pp * 1024), 16, 0, 0);
+  // a finite start state for the rows the images do not cover
+  for (int i = tid * 16; i < 4 * img + 2 * NB * QIMG; i += 512 * 16) *reinterpret_cast<v4i_t*>(smem + i) = v4i_t{0, 0, 0, 0};
+  __syncthreads();
+
+  const int qb = wave;  // compute waves 0 .. NB-1 own one 32-query block each
+  // item n of this workgroup
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  auto item_of = [&](int n, int& fr_, int& hd_) -> bool {
+    const int li = n * per_xcd + slot;
+    const int fl = li / heads;
+    hd_ = li - fl * heads;
+    fr_ = fl * 8 + xcd;
+    return fr_ < n_frames;
+  };
+  auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };  // no release fence: see below
+
+  // ---- the loader wave ----------------------------------------------------------------------------------
+  // The spare wave issues every LDS-DMA of the workgroup, so the compute waves never queue behind the 78 one-KB
+  // transfers of an item (a sixth of their time when each wave staged its share).  Two barriers per item:
+  //   top of item n    : K(n) and Q(n) are in; the other Q image is free          -> Q(n+1)
+  //   middle of item n : V(n) is in; the waves hold their scores, K(n) is dead    -> K(n+2) over it, V(n+1)
+  // so an item's transfers are issued while the compute waves work (28 during their QK product, 50 during the
+  // softmax and PV), each with a lead of one item or more, and the memory pipe of the CU never drains.
+  // vmcnt counts in order: to know that a group has landed, allow exactly the instructions issued after it.
+  if (wave == NB) {
+    int f1, h1, f2, h2;
+    auto sbase_of = [&](int f, int hh) { return (uint32_t)f * tokens * ldq + hh * (HD * 2); };
+    int issued = 0, mark_kq = 0, mark_v = 0;
+    bool have = item_of(0, f1, h1);
+    if (have) {
+      attn_stage_k(srdQ, smem, sbase_of(f1, h1), ldq, Db, lane, np, tokens);
+      attn_stage_q<NB>(srdQ, smem + 4 * img, sbase_of(f1, h1), ldq, lane, tokens);
+      issued += np + 4 * NB;
+      mark_kq = issued;
+      if (item_of(1, f2, h2)) {
+        attn_stage_k(srdQ, smem + 2 * img, sbase_of(f2, h2), ldq, Db, lane, np, tokens);
+        issued += np;
       }
+      attn_stage_v(srdQ, smem + img, sbase_of(f1, h1), ldq, Db, lane, np, tokens);
+      issued += np;
+      mark_v = issued;
     }
-  };
+    for (int n = 0; have; ++n) {
+      const int cur = n & 1;
+      wait_vm_dyn(issued - mark_kq);
+      barrier();
+      const bool have1 = item_of(n + 1, f1, h1);
+      if (have1) {
+        attn_stage_q<NB>(srdQ, smem + 4 * img + (cur ^ 1) * NB * QIMG, sbase_of(f1, h1), ldq, lane, tokens);
+        issued += 4 * NB;
+        mark_kq = issued;  // K(n+1) went out before it
+      }
+      wait_vm_dyn(issued - mark_v);
+      barrier();
+      if (have1 && item_of(n + 2, f2, h2)) {
+        attn_stage_k(srdQ, smem + cur * 2 * img, sbase_of(f2, h2), ldq, Db, lane, np, tokens);
+        issued += np;
+      }
+      if (have1) {
+        attn_stage_v(srdQ, smem + (cur ^ 1) * 2 * img + img, sbase_of(f1, h1), ldq, Db, lane, np, tokens);
+        issued += np;
+        mark_v = issued;
+      }
+      have = have1;
+    }
+    return;
+  }
+  if (wave > NB) return;
 
-  const int qb = wave;
-  const int q = qb * 32 + r;
-  auto load_q = [&](bf16x8 (&qv)[4], int it) {
-    if (qb >= NB) return;
-    const int fr_ = it / heads, hd_ = it - fr_ * heads;
-    const bf16_t* b_ = qkv + (int64_t)fr_ * tokens * ld_qkv + hd_ * HD;
-    const int qc = q < tokens ? q : tokens - 1;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qv[s] = *reinterpret_cast<const bf16x8*>(b_ + (int64_t)qc * ld_qkv + s * 16 + h * 8);
-  };
-  int item = blockIdx.x;
-  bf16x8 qf[4], qn[4];
+  // ---- the compute waves --------------------------------------------------------------------------------
 #if ATTN_STAMPS
   unsigned long long a_w = 0, a_i = 0, a_qk = 0, a_sm = 0, a_pv = 0, a_st = 0;
   const unsigned long long t_begin = astamp();
 #endif
-  if (item < n_items) {
-    stage(item, 0);
-    load_q(qf, item);
-  }
-  for (int n = 0; item < n_items; ++n, item += gridDim.x) {
+  int frame, head, nframe = 0, nhead = 0;
+  bool have = item_of(0, frame, head);
+  for (int n = 0; have; ++n) {
     const int cur = n & 1;
-    const int frame = item / heads, head = item - frame * heads;
-    const unsigned char* Ks = smem + cur * BUF;
-    const unsigned char* Vs = Ks + HALF;
-    // my pieces of this item and my Q were issued one item ago (letting the previous item's stores stay in
-    // flight with a counted vmcnt + raw s_barrier measured slower: 172 vs 159 us)
+    const unsigned char* Ks = smem + cur * 2 * img;
+    const unsigned char* Vs = Ks + img;
+    unsigned char* Qs = qs0 + cur * NB * QIMG;
     PSTAMP(p0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // everyone's pieces have landed and everyone is done reading the other buffer
+    // The output stores of the previous item stay in flight: nothing here waits for them (a raw s_barrier;
+    // __syncthreads() would add the workgroup release fence, i.e. a wait for those stores).
+    barrier();
     PSTAMP(p1);
-    if (item + (int)gridDim.x < n_items) {
-      stage(item + gridDim.x, cur ^ 1);
-      load_q(qn, item + gridDim.x);  // the next item's Q fragments fly during this item's compute
-    }
+    const bool have_next = item_of(n + 1, nframe, nhead);
     PSTAMP(p2);
-    if (qb >= NB) continue;
+    {
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qs + r * 128 + (((2 * s + h) ^ ksw) << 4));
 
     // ---- Sᵀ[key][q] for all NB key blocks (as in the kernel above) ----------------------------------
     f32x16 S[NB];
@@ -393,6 +526,7 @@ __global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __
     __builtin_amdgcn_sched_barrier(0);
     mma_k(kfb, 3);
     __builtin_amdgcn_sched_barrier(0);
+    barrier();  // every wave has read its K fragments (the loader may overwrite the K image); V is in
     PSTAMP(p3);
 
     // ---- softmax over the key axis ------------------------------------------------------------------
@@ -473,9 +607,9 @@ __global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __
     }
 
     PSTAMP(p5);
-    if (q < tokens) {
+    // ---- output: [q][64] bf16 through my (consumed) Q image, then whole 128-byte lines --------------
+    {
       const float inv = 1.0f / l;
-      bf16_t* op = out + ((int64_t)frame * tokens + q) * ld_out + head * HD;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -483,17 +617,28 @@ __global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __
           bf16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(O[dt][4 * g + e] * inv);
-          *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g + 4 * h) = o;
+          *reinterpret_cast<bf16x4*>(Qs + r * 128 + (((4 * dt + g) ^ ksw) << 4) + 8 * h) = o;
         }
-    }
+      const uint32_t obase = (uint32_t)frame * tokens * ldo + head * (HD * 2);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+      for (int i = 0; i < 4; ++i) {
+        const int rl = 8 * i + (lane >> 3), pos = lane & 7;
+        const v4i_t d = *reinterpret_cast<const v4i_t*>(Qs + rl * 128 + ((pos ^ ((rl >> 1) & 7)) << 4));
+        const int qq = qb * 32 + rl;
+        const uint32_t off = qq < tokens ? (uint32_t)qq * ldo + pos * 16 : 0xffffffffu;  // rows past the frame: dropped
+        __builtin_amdgcn_raw_buffer_store_b128(d, srdO, off, obase, 0);
+      }
+    }
 #if ATTN_STAMPS
     {
       const unsigned long long p6 = astamp();
       a_w += p1 - p0; a_i += p2 - p1; a_qk += p3 - p2; a_sm += p4 - p3; a_pv += p5 - p4; a_st += p6 - p5;
     }
 #endif
+    }
+    have = have_next;
+    frame = nframe;
+    head = nhead;
   }
 #if ATTN_STAMPS
   if (lane == 0 && g_attn_dbg && wave < 2) {
@@ -504,22 +649,27 @@ __global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __
 #endif
 }
 
+// 1 = not served (shape outside the persistent kernel's LDS budget or 32-bit offsets)
 template <int NB>
 int launch_persist(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, int n_frames, int tokens, int heads, float scale,
                    hipStream_t st) {
-  constexpr int BYTES = 2 * 2 * NB * 32 * 128;
+  const int64_t lds = (int64_t)4 * tokens * 128 + 2 * NB * 4096;
+  const int64_t qkv_bytes = ((int64_t)n_frames * tokens - 1) * ld_qkv * 2 + (int64_t)3 * heads * HD * 2;
+  const int64_t out_bytes = ((int64_t)n_frames * tokens - 1) * ld_out * 2 + (int64_t)heads * HD * 2;
+  if (lds > 160 * 1024 || qkv_bytes > (int64_t)0xfffffff0 || out_bytes > (int64_t)0xfffffff0 || (ld_qkv % 8) != 0 || (ld_out % 8) != 0) return 1;
   static int ncu = 0;
   if (ncu == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
     if (ncu <= 0) ncu = 256;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_persist_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_persist_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  const int n_items = n_frames * heads;
-  const int grid = n_items < ncu ? n_items : ncu;
-  hipLaunchKernelGGL((attn_mfma_persist_kernel<NB>), dim3(grid), dim3(512), BYTES, st, static_cast<const bf16_t*>(qkv), ld_qkv,
-                     static_cast<bf16_t*>(out), ld_out, tokens, heads, n_items, scale * 1.4426950408889634f);
+  const int grid = ncu & ~7;  // a whole number of workgroups per XCD
+  if (grid < 8) return 1;
+  hipLaunchKernelGGL((attn_mfma_persist_kernel<NB>), dim3(grid), dim3(512), (size_t)lds, st, static_cast<const bf16_t*>(qkv),
+                     (uint32_t)(ld_qkv * 2), static_cast<bf16_t*>(out), (uint32_t)(ld_out * 2), tokens, heads, n_frames,
+                     (uint32_t)qkv_bytes, (uint32_t)out_bytes, scale * 1.4426950408889634f);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     dfd_set_error("dfd_attention_fwd(mfma, persistent): launch failed: %s", hipGetErrorString(e));
@@ -558,10 +708,12 @@ extern "C" void dfd_attn_set_debug(float* p) { (void)hipMemcpyToSymbol(HIP_SYMBO
 int dfd_attention_mfma_try(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, int n_frames, int tokens, int heads,
                            float scale, hipStream_t st) {
   if ((ld_qkv % 8) != 0 || (ld_out % 4) != 0) return 1;
-  // NB = ceil(tokens / 32) exactly: the kernel masks only its last key block
-  static const bool persist = getenv("DFD_ATTN_PERSIST") == nullptr || getenv("DFD_ATTN_PERSIST")[0] != '0';
+  // NB = ceil(tokens / 32) exactly: the kernels mask only their last key block
   if (tokens > 6 * 32 && tokens <= 7 * 32) {
-    if (persist && n_frames * heads >= 512) return launch_persist<7>(qkv, ld_qkv, out, ld_out, n_frames, tokens, heads, scale, st);
+    if (n_frames * heads >= 512) {
+      const int rc = launch_persist<7>(qkv, ld_qkv, out, ld_out, n_frames, tokens, heads, scale, st);
+      if (rc <= 0) return rc;
+    }
     return launch<7>(qkv, ld_qkv, out, ld_out, n_frames, tokens, heads, scale, st);
   }
   if (tokens > 8 * 32 && tokens <= 9 * 32) return launch<9>(qkv, ld_qkv, out, ld_out, n_frames, tokens, heads, scale, st);

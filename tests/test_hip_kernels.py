@@ -338,7 +338,8 @@ def test_gemm_qkv_export_layout(capi, dtype):
     assert torch.equal(ke2, ke) and torch.equal(ve2, ve) and torch.equal(c3[:, D:], c[:, D:]) and (c3[:, :D] == 0).all()
 
 
-@pytest.mark.parametrize("n,tokens,heads", [(2, 5, 2), (3, 197, 4), (1, 257, 2), (2, 50, 12), (64, 197, 12), (45, 200, 12)])
+@pytest.mark.parametrize("n,tokens,heads", [(2, 5, 2), (3, 197, 4), (1, 257, 2), (2, 50, 12), (64, 197, 12), (45, 200, 12),
+                                            (43, 205, 12), (48, 210, 12)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_encoder_attention(capi, n, tokens, heads, dtype):
     D = heads * 64
@@ -354,6 +355,26 @@ def test_encoder_attention(capi, n, tokens, heads, dtype):
         assert_close(out, want, 2e-5, 1e-5, "attention f32")
     else:  # P is rounded to bf16 before the PV product in the MFMA kernel
         assert_close(out, want, 2e-2, 2 ** -7, "attention bf16")
+
+
+@pytest.mark.parametrize("n,tokens", [(64, 197), (45, 200), (43, 205)])
+def test_encoder_attention_persistent_kernel_matches_per_item_kernel(capi, n, tokens):
+    """>= 512 (frame, head) items take the persistent kernel (loader wave + LDS-DMA, two barriers per item); the same
+    frames in chunks below that threshold take the one-workgroup-per-item kernel: same arithmetic, same bits."""
+    heads, D = 12, 768
+    qkv = rnd(n * tokens, 3 * D, seed=23).to(torch.bfloat16).cuda()
+    qkv[:, :D] *= 2.0
+    whole = torch.empty(n * tokens, D, device="cuda", dtype=torch.bfloat16)
+    capi.attention_fwd(qkv, whole, n, tokens, heads)
+    parts = torch.empty_like(whole)
+    step = 16  # 192 items per call
+    for f0 in range(0, n, step):
+        f1 = min(n, f0 + step)
+        capi.attention_fwd(qkv[f0 * tokens:f1 * tokens], parts[f0 * tokens:f1 * tokens], f1 - f0, tokens, heads)
+    assert torch.equal(whole, parts)
+    again = torch.empty_like(whole)
+    capi.attention_fwd(qkv, again, n, tokens, heads)
+    assert torch.equal(whole, again)
 
 
 @pytest.mark.parametrize("B,T,P,heads", [(2, 4, 4, 2), (3, 3, 196, 4), (2, 8, 196, 12), (1, 5, 256, 16)])
