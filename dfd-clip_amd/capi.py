@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT, EPI_RESIDUAL_POS = range(6)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
 FP8 = 2           # ABI code of OCP e4m3; stored in uint8 / torch.float8_e4m3fn tensors
@@ -80,7 +80,7 @@ SIGNATURES = {
     "dfd_attention_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dfd_linear_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "dfd_linear_rows_t_workspace": (c_size_t, [c_int, c_int, c_int]),
-    "dfd_linear_rows_t": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
+    "dfd_linear_rows_t": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                                   c_void_p]),
     "dfd_decoder_attn_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dfd_decoder_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -364,15 +364,18 @@ def linear_rows_t_workspace_bytes(B, N, K):
     return load_library().dfd_linear_rows_t_workspace(B, N, K)
 
 
-def linear_rows_t(x, wt, bias, y, workspace, epilogue=EPI_BIAS):
-    """y[B,N] = epilogue(x[B,K] @ wt[K,N] + bias): forward with wt = weight^T, data gradient with wt = weight."""
-    _dev(x, wt, bias, y, workspace)
+def linear_rows_t(x, wt, bias, y, workspace, epilogue=EPI_BIAS, residual=None):
+    """y[B,N] = epilogue(x[B,K] @ wt[K,N] + bias): forward with wt = weight^T, data gradient with wt = weight.
+    EPI_BIAS_RESIDUAL adds `residual` [B,N] (None: y itself, in place)."""
+    _dev(x, wt, bias, y, workspace, residual)
+    assert residual is None or (residual.dtype == torch.float32 and residual.stride(1) == 1 and residual.shape == y.shape)
     assert x.dtype == torch.float32 and wt.dtype == torch.float32 and y.dtype == torch.float32
     assert x.stride(1) == 1 and y.stride(1) == 1 and wt.is_contiguous()
     B, K = x.shape
     N = wt.shape[1]
     assert wt.shape[0] == K and workspace.numel() * workspace.element_size() >= linear_rows_t_workspace_bytes(B, N, K)
-    _check(load_library().dfd_linear_rows_t(_ptr(x), x.stride(0), _ptr(wt), _ptr(bias), _ptr(y), y.stride(0), epilogue, B, N, K,
+    _check(load_library().dfd_linear_rows_t(_ptr(x), x.stride(0), _ptr(wt), _ptr(bias), _ptr(residual),
+                                            residual.stride(0) if residual is not None else 0, _ptr(y), y.stride(0), epilogue, B, N, K,
                                             _ptr(workspace), _stream()), "dfd_linear_rows_t")
     return y
 

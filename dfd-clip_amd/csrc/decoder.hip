@@ -430,7 +430,8 @@ __global__ __launch_bounds__(256) void linear_t_partial_kernel(const float* __re
 
 template <int EPI>
 __global__ __launch_bounds__(256) void linear_t_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
-                                                              float* __restrict__ y, int64_t ldy, int B, int N, int slabs) {
+                                                              const float* res, int64_t ldr, float* y, int64_t ldy, int B, int N,
+                                                              int slabs) {
   const int idx = blockIdx.x * 256 + threadIdx.x;  // one float4 of one row
   const int nq = N >> 2;
   if (idx >= B * nq) return;
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(256) void linear_t_reduce_kernel(const float* __res
 #pragma unroll
     for (int e = 0; e < 4; ++e) s[e] = quick_gelu(s[e]);
   }
-  if constexpr (EPI == DFD_EPI_BIAS_RESIDUAL) s += *reinterpret_cast<const f32x4*>(yp);
+  if constexpr (EPI == DFD_EPI_BIAS_RESIDUAL) s += *reinterpret_cast<const f32x4*>(res + (int64_t)b * ldr + j);  // res may be y itself
   *reinterpret_cast<f32x4*>(yp) = s;
 }
 
@@ -583,13 +584,20 @@ extern "C" size_t dfd_linear_rows_t_workspace(int B, int N, int K) {
   return (size_t)ks * (B < 16 ? B : 16) * N * sizeof(float);
 }
 
-extern "C" int dfd_linear_rows_t(const float* x, int64_t ldx, const float* Wt, const float* bias, float* y, int64_t ldy,
-                                 int epilogue, int B, int N, int K, void* workspace, void* stream) {
+extern "C" int dfd_linear_rows_t(const float* x, int64_t ldx, const float* Wt, const float* bias, const float* residual,
+                                 int64_t ldr, float* y, int64_t ldy, int epilogue, int B, int N, int K, void* workspace,
+                                 void* stream) {
   DFD_REQUIRE(x && Wt && y && workspace, "dfd_linear_rows_t: null pointer");
   DFD_REQUIRE(B >= 0 && B <= 64 && N > 0 && K > 0 && N % 4 == 0, "dfd_linear_rows_t: bad shape B=%d N=%d K=%d", B, N, K);
   DFD_REQUIRE(ldx >= K && ldy >= N && ldy % 4 == 0, "dfd_linear_rows_t: bad leading dimensions");
   DFD_REQUIRE(dfd_aligned16(Wt) && dfd_aligned16(y) && dfd_aligned16(workspace) && (!bias || dfd_aligned16(bias)),
               "dfd_linear_rows_t: Wt, y, bias and workspace must be 16-byte aligned");
+  if (!residual) {  // in place
+    residual = y;
+    ldr = ldy;
+  }
+  DFD_REQUIRE(epilogue != DFD_EPI_BIAS_RESIDUAL || (dfd_aligned16(residual) && ldr >= N && ldr % 4 == 0),
+              "dfd_linear_rows_t: residual rows must be 16-byte aligned");
   if (B == 0) return DFD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rpw, ks;
@@ -602,15 +610,16 @@ extern "C" int dfd_linear_rows_t(const float* x, int64_t ldx, const float* Wt, c
     DFD_CHECK_LAUNCH("dfd_linear_rows_t(partial)");
     const dim3 rg((bb * (N / 4) + 255) / 256), rb(256);
     float* yb = y + (int64_t)b0 * ldy;
+    const float* rb_ = residual + (int64_t)b0 * ldr;
     switch (epilogue) {
       case DFD_EPI_BIAS:
-        hipLaunchKernelGGL((linear_t_reduce_kernel<DFD_EPI_BIAS>), rg, rb, 0, st, part, bias, yb, ldy, bb, N, ks);
+        hipLaunchKernelGGL((linear_t_reduce_kernel<DFD_EPI_BIAS>), rg, rb, 0, st, part, bias, rb_, ldr, yb, ldy, bb, N, ks);
         break;
       case DFD_EPI_BIAS_QUICKGELU:
-        hipLaunchKernelGGL((linear_t_reduce_kernel<DFD_EPI_BIAS_QUICKGELU>), rg, rb, 0, st, part, bias, yb, ldy, bb, N, ks);
+        hipLaunchKernelGGL((linear_t_reduce_kernel<DFD_EPI_BIAS_QUICKGELU>), rg, rb, 0, st, part, bias, rb_, ldr, yb, ldy, bb, N, ks);
         break;
       case DFD_EPI_BIAS_RESIDUAL:
-        hipLaunchKernelGGL((linear_t_reduce_kernel<DFD_EPI_BIAS_RESIDUAL>), rg, rb, 0, st, part, bias, yb, ldy, bb, N, ks);
+        hipLaunchKernelGGL((linear_t_reduce_kernel<DFD_EPI_BIAS_RESIDUAL>), rg, rb, 0, st, part, bias, rb_, ldr, yb, ldy, bb, N, ks);
         break;
       default:
         dfd_set_error("dfd_linear_rows_t: epilogue %d unsupported", epilogue);

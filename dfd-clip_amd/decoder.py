@@ -214,8 +214,8 @@ class Decoder(RuntimeStateMixin, nn.Module):
         ws = new(capi.decoder_attn_workspace_bytes(B, H, 64, splits) // 4)
         lws = self._lin_ws(B, dev)
 
-        def lin(x_, pre_, y_, epi=capi.EPI_BIAS):
-            capi.linear_rows_t(x_, self._wt(pre_ + "weight", w), g(pre_ + "bias"), y_, lws, epi)
+        def lin(x_, pre_, y_, epi=capi.EPI_BIAS, residual=None):
+            capi.linear_rows_t(x_, self._wt(pre_ + "weight", w), g(pre_ + "bias"), y_, lws, epi, residual=residual)
 
         x0 = g("class_embedding").view(1, D).repeat(B, 1).contiguous()
         x = new(B, D)
@@ -239,14 +239,14 @@ class Decoder(RuntimeStateMixin, nn.Module):
                     capi.decoder_attn_modes_fwd(q, k_all[i], mask, self.attn_modes, sc, aw, B, T, P, H)
                 capi.decoder_attn_fwd(q, k_all[i], v_all[i], mask, mix, stats, ws, splits, B, T, P, H, mix_softmax=mix_s,
                                       ext_weights=aw)
-                x_mid = x_in.clone()
-                lin(mix, pre + "attn.out_proj.", x_mid, capi.EPI_BIAS_RESIDUAL)
+                x_mid = new(B, D)  # x_in stays for the backward pass: the residual is a separate input, not a clone
+                lin(mix, pre + "attn.out_proj.", x_mid, capi.EPI_BIAS_RESIDUAL, residual=x_in)
                 h2, u_pre, uu = new(B, D), new(B, 4 * D), new(B, 4 * D)
                 capi.layernorm(x_mid, g(pre + "ln_2.weight"), g(pre + "ln_2.bias"), h2)
                 lin(h2, pre + "mlp.c_fc.", u_pre)
                 capi.quickgelu(u_pre, uu, drop=self._drop(drop_rng, 1 + i))
-                x = x_mid.clone()
-                lin(uu, pre + "mlp.c_proj.", x, capi.EPI_BIAS_RESIDUAL)
+                x = new(B, D)
+                lin(uu, pre + "mlp.c_proj.", x, capi.EPI_BIAS_RESIDUAL, residual=x_mid)
                 saved["blocks"].append(dict(x_in=x_in, h1=h1, q=q, mix=mix, mix_s=mix_s, stats=stats, x_mid=x_mid, h2=h2,
                                             u_pre=u_pre, u=uu, sc=sc, aw=aw))
             else:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DFD_ABI_VERSION 10
+#define DFD_ABI_VERSION 11
 
 enum { DFD_F32 = 0, DFD_BF16 = 1, DFD_FP8 = 2 /* OCP e4m3 ("e4m3fn"), one byte per element */ };
 
@@ -179,10 +179,12 @@ int dfd_linear_rows(const float* x, int64_t ldx, const float* W, const float* bi
  * Rows of Wt stream fully coalesced and the activations are wave-uniform scalars, so this is the fast
  * form for both the forward (Wt = weightᵀ, kept by the host and refreshed after each optimizer step)
  * and the data gradient (dx = dy · W: pass the weight itself as "Wt").  Deterministic (fixed-order
- * slab reduction).  N % 4 == 0; workspace >= dfd_linear_rows_t_workspace(B, N, K) bytes. */
+ * slab reduction).  N % 4 == 0; workspace >= dfd_linear_rows_t_workspace(B, N, K) bytes.
+ * DFD_EPI_BIAS_RESIDUAL adds `residual` [B, N] (row stride ldr, 16-byte aligned rows); residual == NULL adds the
+ * previous contents of y (in place).  The other epilogues ignore it. */
 size_t dfd_linear_rows_t_workspace(int B, int N, int K);
-int dfd_linear_rows_t(const float* x, int64_t ldx, const float* Wt, const float* bias, float* y, int64_t ldy,
-                      int epilogue, int B, int N, int K, void* workspace, void* stream);
+int dfd_linear_rows_t(const float* x, int64_t ldx, const float* Wt, const float* bias, const float* residual, int64_t ldr,
+                      float* y, int64_t ldy, int epilogue, int B, int N, int K, void* workspace, void* stream);
 
 /* Decoder cross-attention of ONE query per clip over S = T*P exported keys/values, two branches
  * averaged (models.py:136-146): softmax(q_s·k/√d) and tanh(q_c·k/√d)·2σ(−‖q_c−k‖₁/√d); keys of padded

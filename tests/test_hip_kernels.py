@@ -450,6 +450,9 @@ def test_linear_rows_t(capi, B, N, K):
     y = y0.clone().cuda()
     capi.linear_rows_t(x.cuda(), wt, None, y, ws, capi.EPI_BIAS_RESIDUAL)
     assert_close(y, y0.double() + ref - b.double(), 2e-5, 1e-5, "residual, no bias")
+    y3, res = torch.empty(B, N, device="cuda"), y0.cuda()
+    capi.linear_rows_t(x.cuda(), wt, None, y3, ws, capi.EPI_BIAS_RESIDUAL, residual=res)  # residual as a separate input
+    assert torch.equal(y3, y) and torch.equal(res, y0.cuda())
     y2 = torch.empty(B, N, device="cuda")
     capi.linear_rows_t(x.cuda(), wt, b.cuda(), y2, ws)
     capi.linear_rows_t(x.cuda(), wt, b.cuda(), y, ws)
