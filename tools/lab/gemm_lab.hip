@@ -1,4 +1,5 @@
 // Lab: the product's two tuned bf16 GEMM kernels (gemm256.hip = one workgroup per tile, gemm256p.hip = persistent)
+// and the four-wave lab variant (gemm256q_lab.hip, "Q")
 // on the four ViT-B/16 encoder shapes at B16xT30, interleaved rounds in one process; bitwise comparison first.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -6,6 +7,7 @@
 #include <vector>
 #include "../../dfd-clip_amd/csrc/gemm_args.hpp"
 
+int dfd_gemm256q_launch(const GemmArgs& a, int epi, hipStream_t st);  // gemm256q_lab.hip
 void dfd_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fprintf(stderr, "\n"); }
 
 int main() {
@@ -14,7 +16,8 @@ int main() {
       {"c_fc", 3072, 768, DFD_EPI_BIAS_QUICKGELU}, {"qkv_plain", 2304, 768, DFD_EPI_BIAS}, {"c_proj/d", 768, 3072, DFD_EPI_BIAS}, {"out_proj/d", 768, 768, DFD_EPI_BIAS}};
   struct Var { const char* name; int persistent, rows, stream; } vars[] = {
       {"relaunch", 0, 0, 0}, {"relaunch_nt", 0, 0, 1}, {"P256", 1, 256, 0}, {"P256_nt", 1, 256, 1}, {"P224_nt", 1, 224, 1}, {"Pauto_nt", 1, 0, 1},
-      {"relaunch_nt", 0, 0, 1}, {"P256_nt", 1, 256, 1}, {"P224_nt", 1, 224, 1}};
+      {"Q256_nt", 2, 256, 1}, {"Q224_nt", 2, 224, 1}, {"relaunch_nt", 0, 0, 1}, {"P256_nt", 1, 256, 1}, {"P224_nt", 1, 224, 1}, {"Q256_nt", 2, 256, 1},
+      {"Q224_nt", 2, 224, 1}};
   for (auto& sh : shapes) {
     void *A, *W, *C; float* bias;
     hipMalloc(&A, M * sh.K * 2); hipMalloc(&W, (size_t)sh.N * sh.K * 2); hipMalloc(&C, M * sh.N * 2); hipMalloc(&bias, sh.N * 4);
@@ -26,6 +29,7 @@ int main() {
     GemmArgs a{}; a.A = A; a.W = W; a.C = C; a.bias = bias; a.lda = sh.K; a.ldw = sh.K; a.ldc = sh.N; a.M = M; a.N = sh.N; a.K = sh.K;
     auto run = [&](const Var& v) {
       a.tile_rows = v.rows; a.stream_out = v.stream;
+      if (v.persistent == 2) return dfd_gemm256q_launch(a, sh.epi, 0);
       return v.persistent ? dfd_gemm256p_try(a, DFD_BF16, sh.epi, 0) : dfd_gemm256_try(a, DFD_BF16, sh.epi, 0);
     };
     for (int i = 0; i < 20; ++i) run(vars[0]);
@@ -33,7 +37,7 @@ int main() {
     std::vector<unsigned short> c0((size_t)M * sh.N), c1((size_t)M * sh.N);
     hipMemset(C, 0xff, M * sh.N * 2); run(vars[0]); hipDeviceSynchronize();
     hipMemcpy(c0.data(), C, M * sh.N * 2, hipMemcpyDeviceToHost);
-    for (int vi : {3, 4}) {
+    for (int vi : {3, 4, 6, 7}) {
       hipMemset(C, 0xff, M * sh.N * 2); int rc = run(vars[vi]); hipError_t e = hipDeviceSynchronize();
       hipMemcpy(c1.data(), C, M * sh.N * 2, hipMemcpyDeviceToHost);
       size_t bad = 0; for (size_t i = 0; i < c0.size(); ++i) bad += c0[i] != c1[i];
