@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--frame-chunk", type=int, default=-1, help="frames per encoder pass (-1 = package default)")
     ap.add_argument("--streams", type=int, default=-1, help="HIP streams for independent frame chunks (-1 = package default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the informational ViT-L/14 lines (BASELINE configs[3] bf16 / configs[4] fp8) of the default single-GPU run")
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -101,6 +103,40 @@ def build_model(args, device):
         on = set(args.gemm_stream_out.split(",")) - {"none", ""}
         det.encoder.stream_out = {k: k in on for k in det.encoder.stream_out}
     return det, cfg, sd, layers
+
+
+def secondary_configs(args, device):
+    """Informational, outside the headline's timed region, single GPU only: the forward-only rate of the other two
+    encoder configurations BASELINE.json names — configs[3] ViT-L/14 bf16 at 8 clips x 30 frames, and configs[4] the
+    same model with e4m3 operands (static scales calibrated on the synthetic batch) at 8 and at 16 clips x 30."""
+    import copy
+    out = []
+    for prec, clips in (("bf16", 8), ("fp8", 8), ("fp8", 16)):
+        a = copy.copy(args)
+        a.arch, a.precision, a.clips, a.adapter = "ViT-L/14", prec, clips, "none"
+        det, _, _, _ = build_model(a, device)
+        det.eval()
+        g = torch.Generator(device=device).manual_seed(99)
+        x = torch.randn(clips, args.frames, 3, 224, 224, device=device, generator=g)
+        m = torch.ones(clips, args.frames, dtype=torch.bool, device=device)
+        with torch.no_grad():
+            if prec == "fp8":
+                det.calibrate_fp8(x[:2])
+            for _ in range(2):
+                det.predict(x, m)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 5
+            for _ in range(n):
+                det.predict(x, m)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+        out.append({"workload": f"BASELINE configs[{3 if prec == 'bf16' else 4}]: ViT-L/14 forward-only Detector.predict, {clips} clips x "
+                                f"{args.frames} frames, {prec}", "value": round(clips / dt, 2), "unit": "clips/s", "ms_per_step": round(dt * 1e3, 2),
+                    "dtype": prec})
+        del det, x, m
+        torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(cfg, sd, args):
@@ -300,6 +336,8 @@ def main():
             line["config"]["note"] = graph_note
         if fwd_only is not None:
             line["forward_only"] = {"value": round(fwd_only, 3), "unit": "clips/s", "workload": "BASELINE configs[1]: Detector.predict"}
+        if world == 1 and not args.no_secondary and args.arch == "ViT-B/16" and args.precision == "bf16" and args.mode == "train":
+            line["secondary"] = secondary_configs(args, device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, args)
         print(json.dumps(line), flush=True)
