@@ -242,8 +242,41 @@ extern "C" int dfd_add_layernorm(float* x, int64_t ldx, const void* delta, const
 }
 
 // ---- patchify -----------------------------------------------------------------------------
-// One thread per 4 consecutive output columns of one patch row.  Output column
-// k = c*p*p + i*p + j reads frame pixel (c, gy*p + i, gx*p + j).  Reads are contiguous along j
+// Output column k = c*p*p + i*p + j of patch (gy, gx) reads frame pixel (c, gy*p + i, gx*p + j).
+//
+// Strip form (bf16 output, p % 4 == 0, no K padding: ViT-B/16, ViT-B/32): one workgroup per (frame, patch row gy).
+// Its input is 3*p image rows read as whole rows (16 bytes per lane, fully coalesced); its output, the grid_w patch
+// rows of that strip, is ONE contiguous run (grid_w * 3*p*p bf16).  The transpose goes through LDS: a patch's
+// 3*p*p bf16 at stride 3*p*p*2 + 32 bytes (the 8-byte writes of neighbouring patches land 8 banks apart).
+__global__ __launch_bounds__(256) void patchify_strip_kernel(const float* __restrict__ frames, bf16_t* __restrict__ out, int res,
+                                                             int patch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char strip[];
+  const int grid_w = res / patch;
+  const int kk = 3 * patch * patch;
+  const int pstride = kk * 2 + 32;
+  const int n = blockIdx.x / grid_w, gy = blockIdx.x % grid_w;
+  const int qrow = res >> 2;  // 16-byte quads per image row
+  const int nq = 3 * patch * qrow;
+  for (int idx = threadIdx.x; idx < nq; idx += 256) {
+    const int rw = idx / qrow, xq = idx - rw * qrow;  // rw = c*patch + i
+    const int c = rw / patch, i = rw - c * patch;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(frames + (((int64_t)n * 3 + c) * res + (gy * patch + i)) * res + xq * 4);
+    const int x = xq * 4, gx = x / patch, j = x - gx * patch;
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x4*>(strip + gx * pstride + (rw * patch + j) * 2) = o;
+  }
+  __syncthreads();
+  const int cpp = kk >> 3;  // 16-byte chunks per patch
+  bf16_t* dst = out + ((int64_t)n * grid_w * grid_w + (int64_t)gy * grid_w) * kk;
+  for (int idx = threadIdx.x; idx < grid_w * cpp; idx += 256) {
+    const int pp = idx / cpp, ch = idx - pp * cpp;
+    *reinterpret_cast<bf16x8*>(dst + (int64_t)idx * 8) = *reinterpret_cast<const bf16x8*>(strip + pp * pstride + ch * 16);
+  }
+}
+
+// General form: one thread per 4 consecutive output columns of one patch row.  Reads are contiguous along j
 // (p pixels = 64 B for p=16), writes fully coalesced.
 template <typename OutT>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ frames, OutT* __restrict__ out,
@@ -296,6 +329,15 @@ extern "C" int dfd_patchify(const float* frames, void* patches, int out_dtype, i
   const int64_t total = (int64_t)n_frames * P * (kpad / 4);
   const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int kk = 3 * patch * patch;
+  const size_t strip_lds = (size_t)(res / patch) * (kk * 2 + 32);
+  if (out_dtype == DFD_BF16 && patch % 4 == 0 && kpad == kk && strip_lds <= 64 * 1024 && dfd_aligned16(frames) &&
+      (int64_t)n_frames * (res / patch) < (int64_t)0x7fffffff) {
+    hipLaunchKernelGGL(patchify_strip_kernel, dim3((unsigned)(n_frames * (res / patch))), dim3(256), strip_lds, st, frames,
+                       static_cast<bf16_t*>(patches), res, patch);
+    DFD_CHECK_LAUNCH("dfd_patchify(strip)");
+    return DFD_OK;
+  }
   if (out_dtype == DFD_F32)
     hipLaunchKernelGGL((patchify_kernel<float>), dim3(blocks), dim3(256), 0, st, frames, static_cast<float*>(patches), n_frames, res, patch, kpad);
   else

@@ -111,6 +111,21 @@ def test_patch_embed_is_conv1_plus_cls_plus_pos(capi, res, patch, width, dtype):
     assert_close(x.view(n, tokens, width), want, 2e-4 if dtype == torch.float32 else 2e-3, msg="patch embed")
 
 
+@pytest.mark.parametrize("n,res,patch", [(3, 32, 16), (5, 224, 16), (2, 224, 32), (2, 64, 8)])
+def test_patchify_strip_kernel_matches_the_general_one(capi, n, res, patch):
+    """bf16 patches of 4-aligned patch sizes come from the strip kernel (whole image rows in, one contiguous run out,
+    transposed through LDS); the f32 output takes the general kernel: same values, rounded once."""
+    frames = rnd(n, 3, res, res, seed=41).cuda()
+    P, kk = (res // patch) ** 2, 3 * patch * patch
+    a = torch.zeros(n * P, kk, device="cuda", dtype=torch.bfloat16)
+    b = torch.zeros(n * P, kk, device="cuda", dtype=torch.float32)
+    capi.patchify(frames, a, res, patch)
+    capi.patchify(frames, b, res, patch)
+    assert torch.equal(a, b.to(torch.bfloat16))
+    want = frames.view(n, 3, res // patch, patch, res // patch, patch).permute(0, 2, 4, 1, 3, 5).reshape(n * P, kk)
+    assert torch.equal(b, want)
+
+
 @pytest.mark.parametrize("M,N,K", [(5, 8, 32), (300, 200, 64), (591, 384, 128), (1000, 2304, 768), (257, 768, 3072)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_epilogues(capi, M, N, K, dtype):
