@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT, EPI_RESIDUAL_POS = range(6)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
 FP8 = 2           # ABI code of OCP e4m3; stored in uint8 / torch.float8_e4m3fn tensors
@@ -84,15 +84,15 @@ SIGNATURES = {
                                   c_void_p]),
     "dfd_decoder_attn_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dfd_decoder_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dfd_decoder_attn_modes_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                           c_int, c_void_p]),
-    "dfd_decoder_attn_modes_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                           c_int, c_void_p]),
+                                     c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dfd_decoder_attn_modes_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                           c_int, c_int, c_void_p]),
+    "dfd_decoder_attn_modes_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                           c_int, c_int, c_void_p]),
     "dfd_decoder_attn_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dfd_decoder_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                     c_void_p]),
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                     c_int, c_void_p]),
     "dfd_adapter_norm_gelu_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dfd_adapter_norm_gelu_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_int, c_int, c_int, c_int, c_float, c_void_p]),
@@ -384,13 +384,39 @@ def decoder_attn_workspace_bytes(B, heads, d, splits):
     return load_library().dfd_decoder_attn_workspace(B, heads, d, splits)
 
 
+class KvLayoutDesc(ctypes.Structure):
+    """dfd_kv_layout_t"""
+    _fields_ = [("row_stride", c_int64), ("frame_stride", c_int64), ("pos", c_void_p)]
+
+
+def _kv_layout(x, other, pos, B, T, patches, D):
+    """Keys / values as the dense export [B*T*patches, D] (contiguous, any leading shape) or as a strided view
+    [B*T, patches, D] of a larger activation (e.g. qkv[:, 1:, D:2*D] of the encoder's [frames, tokens, 3*D]);
+    `pos` [T, D] f32: temporal positional embedding added on the fly.  Returns (layout or None, keep-alive)."""
+    if other is not None:
+        assert other.dtype == x.dtype and other.shape == x.shape and other.stride() == x.stride()
+    if x.is_contiguous() and pos is None:
+        assert x.numel() == B * T * patches * D
+        return None, None
+    if x.is_contiguous():
+        rs, fs = D, patches * D
+    else:
+        assert x.dim() == 3 and x.shape == (B * T, patches, D) and x.stride(2) == 1, "strided K/V must be [B*T, patches, D] views"
+        fs, rs = x.stride(0), x.stride(1)
+    if pos is not None:
+        assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape == (T, D) and pos.device == x.device
+    lay = KvLayoutDesc(rs, fs, pos.data_ptr() if pos is not None else None)
+    return ctypes.byref(lay), lay
+
+
 def decoder_attn_fwd(q, k, v, frame_mask, mix, stats, workspace, splits, B, T, patches, heads, d=64, mix_softmax=None,
-                     ext_weights=None):
+                     ext_weights=None, pos=None):
     _dev(q, k, v, frame_mask, mix, stats, workspace, mix_softmax, ext_weights)
-    assert q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    assert q.dtype == torch.float32 and q.is_contiguous()
     assert frame_mask.dtype == torch.uint8 and frame_mask.is_contiguous()
     assert ext_weights is None or (ext_weights.is_contiguous() and ext_weights.numel() == B * heads * T * patches)
-    _check(load_library().dfd_decoder_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _DTYPE[k.dtype], _ptr(frame_mask), _ptr(ext_weights),
+    lay, _keep = _kv_layout(k, v, pos, B, T, patches, heads * d)
+    _check(load_library().dfd_decoder_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _DTYPE[k.dtype], lay, _ptr(frame_mask), _ptr(ext_weights),
                                                _ptr(mix), _ptr(mix_softmax), _ptr(stats), _ptr(workspace), splits, B, T, patches,
                                                heads, d, _stream()),
            "dfd_decoder_attn_fwd")
@@ -400,22 +426,24 @@ def decoder_attn_fwd(q, k, v, frame_mask, mix, stats, workspace, splits, B, T, p
 ATTN_MODE_BITS = {"frame": 1, "temporal": 2}
 
 
-def decoder_attn_modes_fwd(q, k, frame_mask, modes, scores, weights, B, T, patches, heads, d=64):
+def decoder_attn_modes_fwd(q, k, frame_mask, modes, scores, weights, B, T, patches, heads, d=64, pos=None):
     """attn_mode softmax branch: scores [B,heads,S] and grouped-softmax weights [B,heads,S]."""
     _dev(q, k, frame_mask, scores, weights)
-    assert q.is_contiguous() and k.is_contiguous() and scores.is_contiguous() and weights.is_contiguous()
+    assert q.is_contiguous() and scores.is_contiguous() and weights.is_contiguous()
     assert scores.numel() == B * heads * T * patches == weights.numel()
-    _check(load_library().dfd_decoder_attn_modes_fwd(_ptr(q), _ptr(k), _DTYPE[k.dtype], _ptr(frame_mask), modes, _ptr(scores),
+    lay, _keep = _kv_layout(k, None, pos, B, T, patches, heads * d)
+    _check(load_library().dfd_decoder_attn_modes_fwd(_ptr(q), _ptr(k), _DTYPE[k.dtype], lay, _ptr(frame_mask), modes, _ptr(scores),
                                                      _ptr(weights), B, T, patches, heads, d, _stream()),
            "dfd_decoder_attn_modes_fwd")
     return weights
 
 
-def decoder_attn_modes_bwd(scores, v, dmix, modes, dwv_ws, dscores, B, T, patches, heads, d=64):
+def decoder_attn_modes_bwd(scores, v, dmix, modes, dwv_ws, dscores, B, T, patches, heads, d=64, pos=None):
     _dev(scores, v, dmix, dwv_ws, dscores)
-    assert scores.is_contiguous() and v.is_contiguous() and dmix.is_contiguous()
+    assert scores.is_contiguous() and dmix.is_contiguous()
     assert dwv_ws.numel() >= B * heads * T * patches and dscores.numel() == B * heads * T * patches
-    _check(load_library().dfd_decoder_attn_modes_bwd(_ptr(scores), _ptr(v), _DTYPE[v.dtype], _ptr(dmix), modes, _ptr(dwv_ws),
+    lay, _keep = _kv_layout(v, None, pos, B, T, patches, heads * d)
+    _check(load_library().dfd_decoder_attn_modes_bwd(_ptr(scores), _ptr(v), _DTYPE[v.dtype], lay, _ptr(dmix), modes, _ptr(dwv_ws),
                                                      _ptr(dscores), B, T, patches, heads, d, _stream()),
            "dfd_decoder_attn_modes_bwd")
     return dscores
@@ -446,11 +474,12 @@ def decoder_attn_bwd_workspace_bytes(B, T, heads, d=64):
 
 
 def decoder_attn_bwd(q, k, v, frame_mask, dmix, mix_softmax, stats, dq, dpos, workspace, B, T, patches, heads, d=64, dk=None,
-                     dv=None, ext_weights=None, ext_dscores=None):
+                     dv=None, ext_weights=None, ext_dscores=None, pos=None):
     _dev(q, k, v, frame_mask, dmix, mix_softmax, stats, dq, dpos, workspace, dk, dv, ext_weights, ext_dscores)
-    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and dmix.is_contiguous()
+    assert q.is_contiguous() and dmix.is_contiguous()
     assert mix_softmax is None or mix_softmax.is_contiguous()
-    _check(load_library().dfd_decoder_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _DTYPE[k.dtype], _ptr(frame_mask), _ptr(dmix),
+    lay, _keep = _kv_layout(k, v, pos, B, T, patches, heads * d)
+    _check(load_library().dfd_decoder_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _DTYPE[k.dtype], lay, _ptr(frame_mask), _ptr(dmix),
                                                _ptr(mix_softmax), _ptr(stats), _ptr(ext_weights), _ptr(ext_dscores), _ptr(dq),
                                                _ptr(dpos), _ptr(dk), _ptr(dv),
                                                _DTYPE[dk.dtype] if dk is not None else F32, _ptr(workspace), B, T, patches,

@@ -64,3 +64,28 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float quick_gelu(float u) {
   return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * DFD_QUICKGELU_SCALE));
 }
+
+// floor(n / d) for 0 <= n < 2^31 as one multiply-high and a shift: mul = ceil(2^(31+s) / d), s = ceil(log2 d)
+struct FastDiv {
+  uint32_t mul, shift, one;
+  static FastDiv make(uint32_t d) {
+    if (d <= 1) return FastDiv{0u, 0u, 1u};
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    const uint64_t m = ((1ull << (31 + s)) + d - 1) / d;
+    return FastDiv{(uint32_t)m, s - 1, 0u};
+  }
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return one ? n : (__umulhi(n, mul) >> shift); }
+};
+
+// Where the decoder's keys / values live (dfd_kv_layout_t of the C ABI, resolved): element (frame f, patch p,
+// channel c) at base + f*frame_stride + p*row_stride + c; `pos` [T, D] f32 (may be NULL) is added to every key and
+// value row of frame f % T as it is read.
+struct KvLayout {
+  int64_t row_stride, frame_stride;
+  const float* pos;
+};
+static inline KvLayout dfd_kv_layout(const dfd_kv_layout_t* l, int patches, int D) {
+  if (l == nullptr) return KvLayout{(int64_t)D, (int64_t)patches * D, nullptr};
+  return KvLayout{l->row_stride, l->frame_stride, l->pos};
+}

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(MAXT) void decoder_attn_partial_kernel(const float*
                                                                     const uint8_t* __restrict__ frame_mask,
                                                                     const float* __restrict__ ext_w,
                                                                     float* __restrict__ ws, int splits, int T_frames,
-                                                                    int patches, int heads, int R) {
+                                                                    int patches, int heads, int R, KvLayout lay,
+                                                                    FastDiv div_patches) {
   extern __shared__ float red[];  // [R][tpr][18]
   const int tpr = heads * 8;
   const int b = blockIdx.y, split = blockIdx.x;
@@ -81,8 +82,10 @@ __global__ __launch_bounds__(MAXT) void decoder_attn_partial_kernel(const float*
 #pragma unroll
   for (int e = 0; e < 8; ++e) { as[e] = 0.f; ac[e] = 0.f; }
 
-  const T* kb = k + (int64_t)b * S * D + hd * HD + sub * 8;
-  const T* vb = v + (int64_t)b * S * D + hd * HD + sub * 8;
+  // row s of clip b = patch (s % patches) of frame b*T + s / patches (KvLayout: dense export or the qkv activation in place)
+  const T* kb = k + (int64_t)b * T_frames * lay.frame_stride + hd * HD + sub * 8;
+  const T* vb = v + (int64_t)b * T_frames * lay.frame_stride + hd * HD + sub * 8;
+  const float* pb = lay.pos ? lay.pos + hd * HD + sub * 8 : nullptr;
   const uint8_t* mb = frame_mask + (int64_t)b * T_frames;
   // every lane of an 8-lane group walks the same rows, so the shuffles below are convergent.
   // Rows are taken four at a time with all eight loads issued before the first use: the loop is a
@@ -90,11 +93,23 @@ __global__ __launch_bounds__(MAXT) void decoder_attn_partial_kernel(const float*
   constexpr int UN = 4;
   for (int s0 = s_begin + rs; s0 < s_end; s0 += UN * R) {
     float kk[UN][8], vv[UN][8];
+    int tf[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int s = min(s0 + u * R, S - 1);  // clamp: rows past the end are loaded but not used
-      Ld8<T>::load(kb + (int64_t)s * D, kk[u]);
-      Ld8<T>::load(vb + (int64_t)s * D, vv[u]);
+      tf[u] = (int)div_patches.div((uint32_t)s);
+      const int64_t off = (int64_t)tf[u] * lay.frame_stride + (int64_t)(s - tf[u] * patches) * lay.row_stride;
+      Ld8<T>::load(kb + off, kk[u]);
+      Ld8<T>::load(vb + off, vv[u]);
+    }
+    if (pb != nullptr) {  // temporal positional embedding of the row's frame, added to the key and the value
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        float pe[8];
+        Ld8<float>::load(pb + (int64_t)tf[u] * D, pe);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kk[u][e] += pe[e]; vv[u][e] += pe[e]; }
+      }
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -110,7 +125,7 @@ __global__ __launch_bounds__(MAXT) void decoder_attn_partial_kernel(const float*
       ds = group8_sum(ds);
       dc = group8_sum(dc);
       l1 = group8_sum(l1);
-      if (mb[s / patches]) {
+      if (mb[tf[u]]) {
         float p;
         if (ext_w != nullptr) {
           // attn_mode: the softmax-branch weight was computed by the grouped-softmax pass
@@ -217,7 +232,8 @@ __global__ __launch_bounds__(1024) void decoder_rowdot_kernel(const float* __res
                                                               const T* __restrict__ X,
                                                               const uint8_t* __restrict__ frame_mask,
                                                               float* __restrict__ out, float scale, float fill, int splits,
-                                                              int T_frames, int patches, int heads, int R) {
+                                                              int T_frames, int patches, int heads, int R, KvLayout lay,
+                                                              FastDiv div_patches) {
   const int tpr = heads * 8;
   const int b = blockIdx.y, split = blockIdx.x;
   const int rs = threadIdx.x / tpr, tr = threadIdx.x % tpr;
@@ -233,16 +249,24 @@ __global__ __launch_bounds__(1024) void decoder_rowdot_kernel(const float* __res
 #pragma unroll
     for (int e = 0; e < 8; ++e) av[e] = ap[e] * scale;
   }
-  const T* xb = X + (int64_t)b * S * D + hd * HD + sub * 8;
+  const T* xb = X + (int64_t)b * T_frames * lay.frame_stride + hd * HD + sub * 8;
+  const float* pb = lay.pos ? lay.pos + hd * HD + sub * 8 : nullptr;
   for (int s = s_begin + rs; s < s_end; s += R) {
     float xx[8];
-    Ld8<T>::load(xb + (int64_t)s * D, xx);
+    const int tf = (int)div_patches.div((uint32_t)s);
+    Ld8<T>::load(xb + (int64_t)tf * lay.frame_stride + (int64_t)(s - tf * patches) * lay.row_stride, xx);
+    if (pb != nullptr) {
+      float pe[8];
+      Ld8<float>::load(pb + (int64_t)tf * D, pe);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xx[e] += pe[e];
+    }
     float d = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) d = fmaf(av[e], xx[e], d);
     d = group8_sum(d);
     if (sub == 0) {
-      const bool ok = frame_mask == nullptr || frame_mask[(int64_t)b * T_frames + s / patches] != 0;
+      const bool ok = frame_mask == nullptr || frame_mask[(int64_t)b * T_frames + tf] != 0;
       out[((int64_t)b * heads + hd) * S + s] = ok ? d : fill;
     }
   }
@@ -478,7 +502,18 @@ extern "C" size_t dfd_decoder_attn_workspace(int B, int heads, int d, int splits
   return (size_t)B * splits * heads * PART * sizeof(float);
 }
 
-extern "C" int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v, int kv_dtype,
+// layout checks shared by the decoder attention entry points
+static int check_kv_layout(const char* who, const dfd_kv_layout_t* l, int kv_dtype, int D) {
+  if (l == nullptr) return DFD_OK;
+  const int per16 = kv_dtype == DFD_F32 ? 4 : 8;
+  DFD_REQUIRE(l->row_stride >= D && l->frame_stride > 0 && l->row_stride % per16 == 0 && l->frame_stride % per16 == 0,
+              "%s: key/value layout: row stride %lld, frame stride %lld (elements; rows must stay 16-byte aligned)", who,
+              (long long)l->row_stride, (long long)l->frame_stride);
+  DFD_REQUIRE(!l->pos || dfd_aligned16(l->pos), "%s: the positional embedding must be 16-byte aligned", who);
+  return DFD_OK;
+}
+
+extern "C" int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v, int kv_dtype, const dfd_kv_layout_t* layout,
                                     const uint8_t* frame_mask, const float* ext_weights, float* mix, float* mix_softmax,
                                     float* stats, void* workspace, int splits, int B, int T, int patches, int heads, int d,
                                     void* stream) {
@@ -488,7 +523,10 @@ extern "C" int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v
   DFD_REQUIRE(splits > 0 && splits <= 4096, "dfd_decoder_attn_fwd: splits=%d", splits);
   DFD_REQUIRE(kv_dtype == DFD_F32 || kv_dtype == DFD_BF16, "dfd_decoder_attn_fwd: kv_dtype=%d", kv_dtype);
   DFD_REQUIRE(dfd_aligned16(k) && dfd_aligned16(v) && dfd_aligned16(q), "dfd_decoder_attn_fwd: pointers must be 16-byte aligned");
+  if (int rc = check_kv_layout("dfd_decoder_attn_fwd", layout, kv_dtype, heads * HD)) return rc;
   if (B == 0) return DFD_OK;
+  const KvLayout lay = dfd_kv_layout(layout, patches, heads * HD);
+  const FastDiv divp = FastDiv::make((uint32_t)patches);
   const int R = rows_per_block(heads);
   const int threads = heads * 8 * R;
   DFD_REQUIRE(threads <= 1024, "dfd_decoder_attn_fwd: heads=%d needs %d threads", heads, threads);
@@ -498,7 +536,7 @@ extern "C" int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v
   float* ws = static_cast<float*>(workspace);
 #define PARTIAL_LAUNCH(KT, MT)                                                                                      \
   hipLaunchKernelGGL((decoder_attn_partial_kernel<KT, MT>), grid, block, lds, st, q, static_cast<const KT*>(k),     \
-                     static_cast<const KT*>(v), frame_mask, ext_weights, ws, splits, T, patches, heads, R)
+                     static_cast<const KT*>(v), frame_mask, ext_weights, ws, splits, T, patches, heads, R, lay, divp)
   if (kv_dtype == DFD_F32) { if (threads <= 512) PARTIAL_LAUNCH(float, 512); else PARTIAL_LAUNCH(float, 1024); }
   else { if (threads <= 512) PARTIAL_LAUNCH(bf16_t, 512); else PARTIAL_LAUNCH(bf16_t, 1024); }
 #undef PARTIAL_LAUNCH
@@ -510,8 +548,11 @@ extern "C" int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v
 }
 
 // shared by the attn_mode entry points (also used from decoder_bwd.hip through dfd_decoder_rowdot)
-int dfd_decoder_rowdot(const float* a, int a_stride, const void* X, int kv_dtype, const uint8_t* frame_mask, float* out,
-                       float scale, float fill, int B, int T, int patches, int heads, hipStream_t st) {
+int dfd_decoder_rowdot(const float* a, int a_stride, const void* X, int kv_dtype, const dfd_kv_layout_t* layout,
+                       const uint8_t* frame_mask, float* out, float scale, float fill, int B, int T, int patches, int heads,
+                       hipStream_t st) {
+  const KvLayout lay = dfd_kv_layout(layout, patches, heads * HD);
+  const FastDiv divp = FastDiv::make((uint32_t)patches);
   const int R = rows_per_block(heads);
   const int threads = heads * 8 * R;
   const int S = T * patches;
@@ -519,17 +560,17 @@ int dfd_decoder_rowdot(const float* a, int a_stride, const void* X, int kv_dtype
   const dim3 grid(splits, B), block(threads);
   if (kv_dtype == DFD_F32)
     hipLaunchKernelGGL((decoder_rowdot_kernel<float>), grid, block, 0, st, a, a_stride, static_cast<const float*>(X), frame_mask,
-                       out, scale, fill, splits, T, patches, heads, R);
+                       out, scale, fill, splits, T, patches, heads, R, lay, divp);
   else
     hipLaunchKernelGGL((decoder_rowdot_kernel<bf16_t>), grid, block, 0, st, a, a_stride, static_cast<const bf16_t*>(X),
-                       frame_mask, out, scale, fill, splits, T, patches, heads, R);
+                       frame_mask, out, scale, fill, splits, T, patches, heads, R, lay, divp);
   DFD_CHECK_LAUNCH("dfd_decoder_rowdot");
   return DFD_OK;
 }
 
-extern "C" int dfd_decoder_attn_modes_fwd(const float* q, const void* k, int kv_dtype, const uint8_t* frame_mask, int modes,
-                                          float* scores, float* weights, int B, int T, int patches, int heads, int d,
-                                          void* stream) {
+extern "C" int dfd_decoder_attn_modes_fwd(const float* q, const void* k, int kv_dtype, const dfd_kv_layout_t* layout,
+                                          const uint8_t* frame_mask, int modes, float* scores, float* weights, int B, int T,
+                                          int patches, int heads, int d, void* stream) {
   DFD_REQUIRE(q && k && frame_mask && scores && weights, "dfd_decoder_attn_modes_fwd: null pointer");
   DFD_REQUIRE(d == HD, "dfd_decoder_attn_modes_fwd: head dim %d, only 64 is supported", d);
   DFD_REQUIRE(B >= 0 && T > 0 && patches > 0 && heads > 0 && heads * HD <= 1024, "dfd_decoder_attn_modes_fwd: bad shape");
@@ -541,7 +582,8 @@ extern "C" int dfd_decoder_attn_modes_fwd(const float* q, const void* k, int kv_
   if (B == 0) return DFD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // softmax-branch scores q_s·k/√d, -inf on padded frames (models.py:103-104); q holds [softmax | CoDA] per head
-  const int rc = dfd_decoder_rowdot(q, 2 * HD, k, kv_dtype, frame_mask, scores, 0.125f, -INFINITY, B, T, patches, heads, st);
+  if (int rc = check_kv_layout("dfd_decoder_attn_modes_fwd", layout, kv_dtype, heads * HD)) return rc;
+  const int rc = dfd_decoder_rowdot(q, 2 * HD, k, kv_dtype, layout, frame_mask, scores, 0.125f, -INFINITY, B, T, patches, heads, st);
   if (rc != DFD_OK) return rc;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decoder_modes_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

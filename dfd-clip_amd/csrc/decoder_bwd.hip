@@ -51,7 +51,7 @@ __global__ __launch_bounds__(MAXT) void decoder_attn_bwd_kernel(const float* __r
                                                                 const float* __restrict__ ext_w,
                                                                 const float* __restrict__ ext_ds, float* __restrict__ part,
                                                                 G* __restrict__ dk_out, G* __restrict__ dv_out,
-                                                                int T_frames, int patches, int heads, int R) {
+                                                                int T_frames, int patches, int heads, int R, KvLayout lay) {
   extern __shared__ float red[];  // [R][tpr][24]
   const int tpr = heads * 8;
   const int t = blockIdx.x, b = blockIdx.y;
@@ -90,8 +90,13 @@ __global__ __launch_bounds__(MAXT) void decoder_attn_bwd_kernel(const float* __r
 
   if (valid) {
     const int s0 = t * patches;
-    const T* kb = k + ((int64_t)b * S + s0) * D + hd * HD + sub * 8;
-    const T* vb = v + ((int64_t)b * S + s0) * D + hd * HD + sub * 8;
+    // this block's frame: rows j*row_stride of frame b*T + t (KvLayout), plus the frame's positional embedding
+    const T* kb = k + ((int64_t)b * T_frames + t) * lay.frame_stride + hd * HD + sub * 8;
+    const T* vb = v + ((int64_t)b * T_frames + t) * lay.frame_stride + hd * HD + sub * 8;
+    float pe[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pe[e] = 0.f;
+    if (lay.pos != nullptr) Ld8<float>::load(lay.pos + (int64_t)t * D + hd * HD + sub * 8, pe);
     // two rows per trip, all four loads issued before the first use (the trip is a latency chain otherwise)
     constexpr int UN = 2;
     for (int j0 = rs; j0 < patches; j0 += UN * R) {
@@ -99,8 +104,10 @@ __global__ __launch_bounds__(MAXT) void decoder_attn_bwd_kernel(const float* __r
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
         const int j = min(j0 + u * R, patches - 1);
-        Ld8<T>::load(kb + (int64_t)j * D, kq[u]);
-        Ld8<T>::load(vb + (int64_t)j * D, vq[u]);
+        Ld8<T>::load(kb + (int64_t)j * lay.row_stride, kq[u]);
+        Ld8<T>::load(vb + (int64_t)j * lay.row_stride, vq[u]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kq[u][e] += pe[e]; vq[u][e] += pe[e]; }
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
@@ -420,7 +427,8 @@ extern "C" size_t dfd_decoder_attn_bwd_workspace(int B, int T, int heads, int d)
   return (size_t)B * T * 3 * heads * HD * sizeof(float);
 }
 
-extern "C" int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v, int kv_dtype, const uint8_t* frame_mask,
+extern "C" int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v, int kv_dtype, const dfd_kv_layout_t* layout,
+                                    const uint8_t* frame_mask,
                                     const float* dmix, const float* mix_softmax, const float* stats,
                                     const float* ext_weights, const float* ext_dscores, float* dq, float* dpos, void* dk,
                                     void* dv, int dkv_dtype, void* workspace, int B, int T, int patches, int heads, int d,
@@ -434,7 +442,15 @@ extern "C" int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v
   DFD_REQUIRE(!dk == !dv, "dfd_decoder_attn_bwd: dk and dv must both be given or both be NULL");
   DFD_REQUIRE(!dk || dkv_dtype == DFD_F32 || dkv_dtype == DFD_BF16, "dfd_decoder_attn_bwd: dkv_dtype=%d", dkv_dtype);
   DFD_REQUIRE(dfd_aligned16(k) && dfd_aligned16(v), "dfd_decoder_attn_bwd: k and v must be 16-byte aligned");
+  if (layout != nullptr) {
+    const int per16 = kv_dtype == DFD_F32 ? 4 : 8;
+    DFD_REQUIRE(layout->row_stride >= heads * HD && layout->frame_stride > 0 && layout->row_stride % per16 == 0 &&
+                    layout->frame_stride % per16 == 0 && (!layout->pos || dfd_aligned16(layout->pos)),
+                "dfd_decoder_attn_bwd: key/value layout: row stride %lld, frame stride %lld (elements; 16-byte aligned rows)",
+                (long long)layout->row_stride, (long long)layout->frame_stride);
+  }
   if (B == 0) return DFD_OK;
+  const KvLayout lay = dfd_kv_layout(layout, patches, heads * HD);
   const int R = rows_per_block(heads);
   const int threads = heads * 8 * R;
   const size_t lds = (size_t)threads * 24 * sizeof(float);
@@ -449,7 +465,7 @@ extern "C" int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
     hipLaunchKernelGGL((decoder_attn_bwd_kernel<KT, GT, MT>), grid, block, lds, st, q, static_cast<const KT*>(k),              \
                        static_cast<const KT*>(v), frame_mask, dmix, mix_softmax, stats, ext_weights, ext_dscores, part,      \
-                       static_cast<GT*>(dk), static_cast<GT*>(dv), T, patches, heads, R);                                    \
+                       static_cast<GT*>(dk), static_cast<GT*>(dv), T, patches, heads, R, lay);                                    \
   } while (0)
   // blocks of <= 512 threads (every even head count) get the 256-register budget: no spills with two rows in flight
 #define BWD_LAUNCH(KT, GT)                                                                                                  \
@@ -468,12 +484,13 @@ extern "C" int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v
   return DFD_OK;
 }
 
-int dfd_decoder_rowdot(const float* a, int a_stride, const void* X, int kv_dtype, const uint8_t* frame_mask, float* out,
-                       float scale, float fill, int B, int T, int patches, int heads, hipStream_t st);  // decoder.hip
+int dfd_decoder_rowdot(const float* a, int a_stride, const void* X, int kv_dtype, const dfd_kv_layout_t* layout,
+                       const uint8_t* frame_mask, float* out, float scale, float fill, int B, int T, int patches, int heads,
+                       hipStream_t st);  // decoder.hip
 
-extern "C" int dfd_decoder_attn_modes_bwd(const float* scores, const void* v, int kv_dtype, const float* dmix, int modes,
-                                          float* dwv_workspace, float* dscores, int B, int T, int patches, int heads, int d,
-                                          void* stream) {
+extern "C" int dfd_decoder_attn_modes_bwd(const float* scores, const void* v, int kv_dtype, const dfd_kv_layout_t* layout,
+                                          const float* dmix, int modes, float* dwv_workspace, float* dscores, int B, int T,
+                                          int patches, int heads, int d, void* stream) {
   DFD_REQUIRE(scores && v && dmix && dwv_workspace && dscores, "dfd_decoder_attn_modes_bwd: null pointer");
   DFD_REQUIRE(d == HD, "dfd_decoder_attn_modes_bwd: head dim %d, only 64 is supported", d);
   DFD_REQUIRE(B >= 0 && T > 0 && patches > 0 && heads > 0 && heads * HD <= 1024, "dfd_decoder_attn_modes_bwd: bad shape");
@@ -485,7 +502,7 @@ extern "C" int dfd_decoder_attn_modes_bwd(const float* scores, const void* v, in
   if (B == 0) return DFD_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // dL/d(weight of key s) = dmix · v_s  (weights multiply v in the mix, models.py:144)
-  const int rc = dfd_decoder_rowdot(dmix, HD, v, kv_dtype, nullptr, dwv_workspace, 1.0f, 0.f, B, T, patches, heads, st);
+  const int rc = dfd_decoder_rowdot(dmix, HD, v, kv_dtype, layout, nullptr, dwv_workspace, 1.0f, 0.f, B, T, patches, heads, st);
   if (rc != DFD_OK) return rc;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decoder_modes_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

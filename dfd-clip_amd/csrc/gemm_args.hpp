@@ -2,19 +2,6 @@
 #pragma once
 #include "dropout.hpp"
 
-// floor(n / d) for 0 <= n < 2^31 as one multiply-high and a shift: mul = ceil(2^(31+s) / d), s = ceil(log2 d)
-struct FastDiv {
-  uint32_t mul, shift, one;
-  static FastDiv make(uint32_t d) {
-    if (d <= 1) return FastDiv{0u, 0u, 1u};
-    uint32_t s = 0;
-    while ((1ull << s) < d) ++s;
-    const uint64_t m = ((1ull << (31 + s)) + d - 1) / d;
-    return FastDiv{(uint32_t)m, s - 1, 0u};
-  }
-  __device__ __forceinline__ uint32_t div(uint32_t n) const { return one ? n : (__umulhi(n, mul) >> shift); }
-};
-
 struct GemmArgs {
   const void* A;
   const void* W;

@@ -142,17 +142,29 @@ class Decoder(RuntimeStateMixin, nn.Module):
 
     # ---- plumbing ------------------------------------------------------------------------------
     def _unpack(self, kvs, m):
+        """-> (k_all, v_all, kv_pos, mask, B, T, P).  K/V come as the dense export [L, B*T*P, D] (positional embedding
+        already added; kv_pos None), or IN PLACE: (k, v, pos) with k, v strided views [L, B*T, P, D] of the encoder's
+        q|k|v activations and pos [T, D] f32 (or None) added by the attention kernels as they read the rows."""
+        kv_pos = None
         if isinstance(kvs, list):
             k_all, v_all = self._pack(kvs)
+        elif len(kvs) == 3:
+            k_all, v_all, kv_pos = kvs
         else:
             k_all, v_all = kvs
         if not k_all.is_cuda:
             raise capi.DfdError("the decoder runs on HIP kernels only: pass device tensors")
         B, T = m.shape
-        S = k_all.shape[1] // B
-        assert k_all.shape[0] == len(self.layer_indices) and S % T == 0 and k_all.shape[2] == self.width
+        if k_all.dim() == 4:
+            assert k_all.shape[1] == B * T and v_all.shape == k_all.shape and v_all.stride() == k_all.stride()
+            P = k_all.shape[2]
+        else:
+            S = k_all.shape[1] // B
+            assert S % T == 0
+            P = S // T
+        assert k_all.shape[0] == len(self.layer_indices) and k_all.shape[-1] == self.width
         mask = m.to(device=k_all.device, dtype=torch.uint8).contiguous()
-        return k_all, v_all, mask, B, T, S // T
+        return k_all, v_all, kv_pos, mask, B, T, P
 
     def _wt(self, name, w):
         """Transposed [K, N] copy of Linear weight `name`, refreshed when the parameter changed (its
@@ -188,7 +200,7 @@ class Decoder(RuntimeStateMixin, nn.Module):
         """-> (raw logits list, video_feature, normalised logits list).  With grad enabled and any
         trainable parameter, goes through `_DecoderFn` so `loss.backward()` reaches the parameters.
         `drop_rng`: this step's dropout state (device int64 {seed, step}) in train mode, None = no dropout."""
-        k_all, v_all, mask, B, T, P = self._unpack(kvs, m)
+        k_all, v_all, kv_pos, mask, B, T, P = self._unpack(kvs, m)
         if self.dropout_p <= 0:
             drop_rng = None
         if self._param_list is None:  # the module tree is static: walk it once, not every step
@@ -196,15 +208,15 @@ class Decoder(RuntimeStateMixin, nn.Module):
         names = [n for n, p in self._param_list]
         params = [p for n, p in self._param_list]
         if torch.is_grad_enabled() and (any(p.requires_grad for p in params) or k_all.requires_grad):
-            out = _DecoderFn.apply(self, k_all, v_all, mask, (B, T, P), names, drop_rng, *params)
+            out = _DecoderFn.apply(self, k_all, v_all, mask, (B, T, P), names, (drop_rng, kv_pos), *params)
             n = len(self.out_dims)
             return list(out[1:1 + n]), out[0], list(out[1 + n:1 + 2 * n])
         w = {n: p.detach() for n, p in zip(names, params)}
-        raws, feat, outs, _ = self._forward_kernels(w, k_all, v_all, mask, B, T, P, save=False, drop_rng=drop_rng)
+        raws, feat, outs, _ = self._forward_kernels(w, k_all, v_all, mask, B, T, P, save=False, drop_rng=drop_rng, kv_pos=kv_pos)
         return raws, feat, outs
 
     # ---- forward on HIP kernels --------------------------------------------------------------
-    def _forward_kernels(self, w, k_all, v_all, mask, B, T, P, save, drop_rng=None):
+    def _forward_kernels(self, w, k_all, v_all, mask, B, T, P, save, drop_rng=None, kv_pos=None):
         dev = k_all.device
         D, H, L = self.width, self.heads, k_all.shape[0]
         f32 = dict(device=dev, dtype=torch.float32)
@@ -222,7 +234,7 @@ class Decoder(RuntimeStateMixin, nn.Module):
         capi.layernorm(x0, g("ln_pre.weight"), g("ln_pre.bias"), x)
         if self._drop(drop_rng, 0) is not None:
             capi.dropout(x, x, self._drop(drop_rng, 0))  # drop_pre (models.py:337)
-        saved = dict(x0=x0, blocks=[], drop_rng=drop_rng)
+        saved = dict(x0=x0, blocks=[], drop_rng=drop_rng, kv_pos=kv_pos)
         xs = []  # per-block outputs, read by the per-layer heads of `global_prediction`
         mode_ws = None
         h, q, mix, stats, u = new(B, D), new(B, 2 * D), new(B, D), new(B, H, 2), new(B, 4 * D)
@@ -236,9 +248,9 @@ class Decoder(RuntimeStateMixin, nn.Module):
                 sc = aw = None
                 if self.attn_modes:
                     sc, aw = new(B, H, T * P), new(B, H, T * P)
-                    capi.decoder_attn_modes_fwd(q, k_all[i], mask, self.attn_modes, sc, aw, B, T, P, H)
+                    capi.decoder_attn_modes_fwd(q, k_all[i], mask, self.attn_modes, sc, aw, B, T, P, H, pos=kv_pos)
                 capi.decoder_attn_fwd(q, k_all[i], v_all[i], mask, mix, stats, ws, splits, B, T, P, H, mix_softmax=mix_s,
-                                      ext_weights=aw)
+                                      ext_weights=aw, pos=kv_pos)
                 x_mid = new(B, D)  # x_in stays for the backward pass: the residual is a separate input, not a clone
                 lin(mix, pre + "attn.out_proj.", x_mid, capi.EPI_BIAS_RESIDUAL, residual=x_in)
                 h2, u_pre, uu = new(B, D), new(B, 4 * D), new(B, 4 * D)
@@ -256,8 +268,8 @@ class Decoder(RuntimeStateMixin, nn.Module):
                 if self.attn_modes:
                     if mode_ws is None:
                         mode_ws = (new(B, H, T * P), new(B, H, T * P))
-                    aw = capi.decoder_attn_modes_fwd(q, k_all[i], mask, self.attn_modes, mode_ws[0], mode_ws[1], B, T, P, H)
-                capi.decoder_attn_fwd(q, k_all[i], v_all[i], mask, mix, stats, ws, splits, B, T, P, H, ext_weights=aw)
+                    aw = capi.decoder_attn_modes_fwd(q, k_all[i], mask, self.attn_modes, mode_ws[0], mode_ws[1], B, T, P, H, pos=kv_pos)
+                capi.decoder_attn_fwd(q, k_all[i], v_all[i], mask, mix, stats, ws, splits, B, T, P, H, ext_weights=aw, pos=kv_pos)
                 lin(mix, pre + "attn.out_proj.", x, capi.EPI_BIAS_RESIDUAL)
                 capi.layernorm(x, g(pre + "ln_2.weight"), g(pre + "ln_2.bias"), h)
                 lin(h, pre + "mlp.c_fc.", u, capi.EPI_BIAS_QUICKGELU)
@@ -315,6 +327,7 @@ class Decoder(RuntimeStateMixin, nn.Module):
         xhat = new(B, D)
         lws = self._lin_ws(B, dev)
         drop_rng = saved.get("drop_rng")
+        kv_pos = saved.get("kv_pos")
 
         def lin_bwd(pre, dy, x_act, want_dx=True):
             """dy [B,N] -> grads of Linear `pre` (weight [N,K], bias) and, optionally, dx [B,K]."""
@@ -394,6 +407,7 @@ class Decoder(RuntimeStateMixin, nn.Module):
         ws = new(capi.decoder_attn_bwd_workspace_bytes(B, T, H) // 4)
         has_pos = "positional_embedding" in w
         dpos_total = torch.zeros(T, D, **f32) if has_pos else None
+        assert not (want_dkv and k_all.dim() == 4), "K/V gradients are produced for the dense export only"
         dk_all = torch.empty_like(k_all) if want_dkv else None
         dv_all = torch.empty_like(v_all) if want_dkv else None
         for i in reversed(range(L)):
@@ -419,10 +433,10 @@ class Decoder(RuntimeStateMixin, nn.Module):
             dsc = None
             if self.attn_modes:
                 dsc = new(B, H, T * P)
-                capi.decoder_attn_modes_bwd(sv["sc"], v_all[i], dmix, self.attn_modes, new(B, H, T * P), dsc, B, T, P, H)
+                capi.decoder_attn_modes_bwd(sv["sc"], v_all[i], dmix, self.attn_modes, new(B, H, T * P), dsc, B, T, P, H, pos=kv_pos)
             capi.decoder_attn_bwd(sv["q"], k_all[i], v_all[i], mask, dmix, sv["mix_s"], sv["stats"], dq, dpos, ws, B, T, P, H,
                                   dk=dk_all[i] if want_dkv else None, dv=dv_all[i] if want_dkv else None,
-                                  ext_weights=sv["aw"], ext_dscores=dsc)
+                                  ext_weights=sv["aw"], ext_dscores=dsc, pos=kv_pos)
             if has_pos:
                 dpos_total += dpos
             dh1 = lin_bwd(pre + "attn.in_proj.", dq, sv["h1"])
@@ -445,13 +459,14 @@ class Decoder(RuntimeStateMixin, nn.Module):
 
 
     # ---- HIP-graph replay of the training-step kernel sequences --------------------------------
-    def _graph_key(self, k_all, v_all, mask, dims, params, dropping):
-        return (k_all.data_ptr(), v_all.data_ptr(), str(k_all.dtype), tuple(k_all.shape), dims, tuple(mask.shape),
+    def _graph_key(self, k_all, v_all, mask, dims, params, dropping, kv_pos=None):
+        return (k_all.data_ptr(), v_all.data_ptr(), str(k_all.dtype), tuple(k_all.shape), tuple(k_all.stride()), dims, tuple(mask.shape),
+                None if kv_pos is None else kv_pos.data_ptr(),
                 tuple(p.data_ptr() for p in params), self.attn_modes, self.global_prediction, dropping, self.dropout_p)
 
-    def _graph_forward(self, w, k_all, v_all, mask, dims, params, drop_rng=None):
+    def _graph_forward(self, w, k_all, v_all, mask, dims, params, drop_rng=None, kv_pos=None):
         B, T, P = dims
-        key = self._graph_key(k_all, v_all, mask, dims, params, drop_rng is not None)
+        key = self._graph_key(k_all, v_all, mask, dims, params, drop_rng is not None, kv_pos)
         graphs = _GRAPHS.setdefault(self, {})
         ent = graphs.get(key)
         if ent is None:
@@ -460,12 +475,12 @@ class Decoder(RuntimeStateMixin, nn.Module):
             # the dropout state is read from device memory by the kernels: the graph owns a static copy that is
             # refreshed before every replay, so each step draws new masks and its backward regenerates them
             ent = dict(mask=mask.clone(), bwd={}, rng=None if drop_rng is None else drop_rng.clone())
-            self._forward_kernels(w, k_all, v_all, ent["mask"], B, T, P, save=True, drop_rng=ent["rng"])  # eager once: lazy initialisations
+            self._forward_kernels(w, k_all, v_all, ent["mask"], B, T, P, save=True, drop_rng=ent["rng"], kv_pos=kv_pos)  # eager once: lazy initialisations
             self._wt_cache.clear()  # the weight transposes must be nodes of the graph (weights change every step)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                raws, feat, outs, saved = self._forward_kernels(w, k_all, v_all, ent["mask"], B, T, P, save=True, drop_rng=ent["rng"])
+                raws, feat, outs, saved = self._forward_kernels(w, k_all, v_all, ent["mask"], B, T, P, save=True, drop_rng=ent["rng"], kv_pos=kv_pos)
             ent.update(fwd=g, raws=raws, feat=feat, outs=outs, saved=saved)
             graphs[key] = ent
         ent["mask"].copy_(mask)
@@ -514,15 +529,16 @@ class _DecoderFn(torch.autograd.Function):
     Outputs: (video_feature, *raw_logits, *normalised_logits)."""
 
     @staticmethod
-    def forward(ctx, dec, k_all, v_all, mask, dims, names, drop_rng, *params):
+    def forward(ctx, dec, k_all, v_all, mask, dims, names, extra, *params):
         B, T, P = dims
+        drop_rng, kv_pos = extra
         w = {n: p.detach() for n, p in zip(names, params)}
-        ent = dec._graph_forward(w, k_all, v_all, mask, dims, params, drop_rng) if dec.use_graphs else None
+        ent = dec._graph_forward(w, k_all, v_all, mask, dims, params, drop_rng, kv_pos) if dec.use_graphs else None
         if ent is not None:  # replayed graph: outputs live in the graph's static buffers, hand out copies
             raws, outs = [t.clone() for t in ent["raws"]], [t.clone() for t in ent["outs"]]
             feat, saved = ent["feat"].clone(), ent["saved"]
         else:
-            raws, feat, outs, saved = dec._forward_kernels(w, k_all, v_all, mask, B, T, P, save=True, drop_rng=drop_rng)
+            raws, feat, outs, saved = dec._forward_kernels(w, k_all, v_all, mask, B, T, P, save=True, drop_rng=drop_rng, kv_pos=kv_pos)
         ctx.graph_entry = ent
         ctx.after_backward, dec._after_backward = dec._after_backward, None
         ctx.dec, ctx.w, ctx.saved, ctx.dims, ctx.names = dec, w, saved, dims, names

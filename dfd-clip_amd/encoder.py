@@ -352,7 +352,7 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         sp = self.spare_cus if (self.spare_layers <= 0 or bp["idx"] < self.spare_layers) else 0
         D = self.width
         # q | k | v projection (+ K/V export); the last tapped layer computes only the K and V thirds
-        first = 1 if (export is not None and kv_only) else 0
+        first = 1 if kv_only else 0
         rows = slice(D, None) if first else slice(None)
         kw = dict(m=M, tokens=self.tokens, qkv_first=first, stream_out=so["qkv"], spare_cus=sp)
         if export is not None:
@@ -414,14 +414,19 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         return result
 
     @torch.no_grad()
-    def extract_kv(self, x, layer_indices, num_frames, temporal_pos=None, out=None, pos_ready=None):
+    def extract_kv(self, x, layer_indices, num_frames, temporal_pos=None, out=None, pos_ready=None, in_place=None):
         """Fused extraction for the decoder: frames [N,3,R,R] (N = B*T) ->
         (k, v): two tensors [L, N*P, D] in the activation dtype, one slab per selected layer,
         rows ordered (clip, frame, patch) — i.e. `[B, T*P, heads, 64]` per layer — with the
         temporal positional embedding `temporal_pos` [T, D] (f32) added when given.
         `pos_ready`: an event that must have fired before `temporal_pos` is read (the pipelined encoder
         stream, `Detector._encode`): waited for right before the first tapped layer's projection, so the
-        layers below it do not wait."""
+        layers below it do not wait.
+        `in_place`: a buffer [L, N, tokens, 3*D] (activation dtype).  The tapped layers then write their q|k|v
+        activation THERE instead of into the shared workspace and nothing is exported: the return value is a pair of
+        strided views [L, N, P, D] (k = buffer[:, :, 1:, D:2D], v = [..., 2D:]) WITHOUT the positional embedding —
+        the decoder's attention kernels read them in place and add it on the fly (`Decoder.run((k, v, pos), m)`).
+        Saves the export's writes (2/3 of a projection's output per tapped layer)."""
         if not x.is_cuda:
             raise capi.DfdError("the encoder runs on HIP kernels only: pass device tensors")
         p = self._prepare()
@@ -432,7 +437,10 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         D, tok = self.width, self.tokens
         P = tok - 1
         L = len(layer_indices)
-        if out is None:
+        if in_place is not None:
+            assert in_place.shape == (L, n, tok, 3 * D) and in_place.dtype == self.act_dtype and in_place.is_contiguous()
+            k_out = v_out = None
+        elif out is None:
             k_out = torch.empty(L, n * P, D, device=frames.device, dtype=self.act_dtype)
             v_out = torch.empty_like(k_out)
         else:
@@ -460,17 +468,22 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
                 qkv = ws["qkv"][0]
                 M = nf * tok
                 self._embed(frames[f0:f0 + nf], ws, p)
-                waited = pos_ready is None or temporal_pos is None
+                waited = pos_ready is None or temporal_pos is None or in_place is not None
                 for l in range(last + 1):
                     exp = None
-                    if l in slot:
+                    qkv_l = qkv
+                    if l in slot and in_place is not None:
+                        qkv_l = in_place[slot[l]].view(n * tok, 3 * D)[f0 * tok:(f0 + nf) * tok]
+                    elif l in slot:
                         i = slot[l]
                         if not waited:
                             torch.cuda.current_stream().wait_event(pos_ready)
                             waited = True
                         exp = (k_out[i, f0 * P:(f0 + nf) * P], v_out[i, f0 * P:(f0 + nf) * P], temporal_pos, num_frames)
-                    self._block(ws, p["blocks"][l], qkv, M, nf, kv_only=(l == last), export=exp)
+                    self._block(ws, p["blocks"][l], qkv_l, M, nf, kv_only=(l == last), export=exp)
         if n_str > 1:
             for st in self._side_streams[:n_str]:
                 cur.wait_stream(st)
+        if in_place is not None:
+            return in_place[:, :, 1:, D:2 * D], in_place[:, :, 1:, 2 * D:]
         return k_out, v_out

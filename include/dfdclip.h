@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DFD_ABI_VERSION 11
+#define DFD_ABI_VERSION 12
 
 enum { DFD_F32 = 0, DFD_BF16 = 1, DFD_FP8 = 2 /* OCP e4m3 ("e4m3fn"), one byte per element */ };
 
@@ -186,6 +186,18 @@ size_t dfd_linear_rows_t_workspace(int B, int N, int K);
 int dfd_linear_rows_t(const float* x, int64_t ldx, const float* Wt, const float* bias, const float* residual, int64_t ldr,
                       float* y, int64_t ldy, int epilogue, int B, int N, int K, void* workspace, void* stream);
 
+/* Where the decoder's keys / values live.  NULL = the dense export: [B, T*patches, heads*d] rows of heads*d elements.
+ * Otherwise element (frame f = clip*T + t, patch p, channel c) is read at base + f*frame_stride + p*row_stride + c
+ * (strides in ELEMENTS; rows 16-byte aligned), and `pos` [T, heads*d] f32 (may be NULL) is added to every key AND
+ * value row of frame t as it is read — models.py:326-329's `kv + temporal positional embedding` done on the fly.
+ * This is the layout of the encoder's q|k|v activation [frames, tokens, 3*heads*d] read in place with the CLS row
+ * skipped (k = qkv + 3*D + D, v = qkv + 3*D + 2*D, row_stride = 3*D, frame_stride = tokens*3*D): the encoder then
+ * writes no export at all. */
+typedef struct {
+  int64_t row_stride, frame_stride;
+  const float* pos;
+} dfd_kv_layout_t;
+
 /* Decoder cross-attention of ONE query per clip over S = T*P exported keys/values, two branches
  * averaged (models.py:136-146): softmax(q_s·k/√d) and tanh(q_c·k/√d)·2σ(−‖q_c−k‖₁/√d); keys of padded
  * frames (frame_mask[b,t] == 0) get weight 0 in both (models.py:104, :124).
@@ -198,9 +210,9 @@ int dfd_linear_rows_t(const float* x, int64_t ldx, const float* Wt, const float*
  *   stats      f32 [B, heads, 2] = (row max, sum of exp) of the softmax branch, kept for backward
  *   workspace  f32, at least dfd_decoder_attn_workspace(B, heads, d, splits) bytes. */
 size_t dfd_decoder_attn_workspace(int B, int heads, int d, int splits);
-int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v, int kv_dtype, const uint8_t* frame_mask,
-                         const float* ext_weights, float* mix, float* mix_softmax, float* stats, void* workspace,
-                         int splits, int B, int T, int patches, int heads, int d, void* stream);
+int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v, int kv_dtype, const dfd_kv_layout_t* layout,
+                         const uint8_t* frame_mask, const float* ext_weights, float* mix, float* mix_softmax, float* stats,
+                         void* workspace, int splits, int B, int T, int patches, int heads, int d, void* stream);
 
 /* op_mode.attn_mode (models.py:107-115): the softmax branch becomes a sum of grouped softmaxes of the
  * scores viewed [T, patches] — bit 0 of `modes` = "frame" (over the patches of each frame), bit 1 =
@@ -208,8 +220,9 @@ int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v, int kv_dt
  * padded frames) and weights [B, heads, S] = Σ_modes softmax_mode(scores); pass `weights` to
  * dfd_decoder_attn_fwd as ext_weights (mix_softmax / stats are then not meaningful).  A group with
  * every key padded yields NaN, as in the reference. */
-int dfd_decoder_attn_modes_fwd(const float* q, const void* k, int kv_dtype, const uint8_t* frame_mask, int modes,
-                               float* scores, float* weights, int B, int T, int patches, int heads, int d, void* stream);
+int dfd_decoder_attn_modes_fwd(const float* q, const void* k, int kv_dtype, const dfd_kv_layout_t* layout,
+                               const uint8_t* frame_mask, int modes, float* scores, float* weights, int B, int T, int patches,
+                               int heads, int d, void* stream);
 
 /* Head: video_feature = LayerNorm(x) (ln_post), z = video_feature @ proj [D, out_dim],
  * logits = 5 z / (‖z‖₂ + 1e-10)  (models.py:342-343, :359, :551-553).  All f32. */
@@ -252,17 +265,17 @@ int dfd_adapter_norm_gelu_bwd(const void* a, int a_dtype, const void* dy, void* 
  *   dmix, mix_softmax [B, heads*d], stats [B, heads, 2] from the forward;
  *   workspace >= dfd_decoder_attn_bwd_workspace(B, T, heads, d) bytes. */
 size_t dfd_decoder_attn_bwd_workspace(int B, int T, int heads, int d);
-int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v, int kv_dtype, const uint8_t* frame_mask,
-                         const float* dmix, const float* mix_softmax, const float* stats, const float* ext_weights,
+int dfd_decoder_attn_bwd(const float* q, const void* k, const void* v, int kv_dtype, const dfd_kv_layout_t* layout,
+                         const uint8_t* frame_mask, const float* dmix, const float* mix_softmax, const float* stats, const float* ext_weights,
                          const float* ext_dscores, float* dq, float* dpos, void* dk, void* dv, int dkv_dtype,
                          void* workspace, int B, int T, int patches, int heads, int d, void* stream);
 
 /* attn_mode backward, first half: from the forward's scores and dmix, dscores [B, heads, S] = dL/d(scores)
  * through the grouped softmaxes.  dwv_workspace: f32 [B, heads, S].  Then call dfd_decoder_attn_bwd with
  * ext_weights = the forward's weights and ext_dscores = dscores (mix_softmax / stats may be NULL). */
-int dfd_decoder_attn_modes_bwd(const float* scores, const void* v, int kv_dtype, const float* dmix, int modes,
-                               float* dwv_workspace, float* dscores, int B, int T, int patches, int heads, int d,
-                               void* stream);
+int dfd_decoder_attn_modes_bwd(const float* scores, const void* v, int kv_dtype, const dfd_kv_layout_t* layout,
+                               const float* dmix, int modes, float* dwv_workspace, float* dscores, int B, int T, int patches,
+                               int heads, int d, void* stream);
 
 /* dW[N,K] = dyᵀ x, db[N] = Σ_b dy (db may be NULL): weight gradient of dfd_linear_rows. */
 int dfd_linear_rows_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dW, float* db, int B,

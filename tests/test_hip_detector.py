@@ -49,6 +49,34 @@ def test_detector_logits_match_reference(name, precision):
     np.testing.assert_allclose(logits[0].norm(dim=-1).cpu().numpy(), 5.0, atol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["tiny", "tiny_nopos", "tiny_attnmode", "tiny_global", "small14", "vitb16_cfg1"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_kv_in_place_matches_the_export_path(name, precision):
+    """Default without an adapter: the decoder reads keys / values out of the tapped layers' q|k|v activations and
+    adds the positional embedding on the fly (`Detector.kv_in_place`).  Against the export path (K/V + pos written
+    by the projection's epilogue): identical in fp32; in bf16 the export rounds k + pos once while the in-place
+    read adds pos to the rounded k — within bf16 rounding of the keys.  Training gradients likewise."""
+    case = build_case(name)
+    x, m, y = case["x"].cuda(), case["m"].cuda(), case["y"].cuda()
+    outs = []
+    for in_place in (True, False):
+        det = make_detector(case, precision).train()
+        det.seed_dropout(123)  # the same masks in both runs
+        det.kv_in_place = in_place
+        det.zero_grad(set_to_none=True)
+        losses, logits, other = det(x, [y], m, train=True, single_task=0)
+        (losses[0].mean() + sum(other.values())).backward()
+        grads = {n: p.grad.clone() for n, p in det.named_parameters() if p.grad is not None}
+        outs.append((logits[0].detach(), grads))
+    (la, ga), (lb, gb) = outs
+    assert ga.keys() == gb.keys() and len(ga) > 10
+    tol = 1e-5 if precision == "fp32" else 3e-2
+    assert (la - lb).abs().max().item() <= tol
+    for n in ga:
+        scale = max(gb[n].abs().max().item(), 1e-6)
+        assert (ga[n] - gb[n]).abs().max().item() <= (1e-4 if precision == "fp32" else 5e-2) * scale, n
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_encoder_reference_api_per_layer(precision):
     """`encoder(x, with_out, with_q)` returns the reference's per-block dicts (clip/model.py:276-294)."""

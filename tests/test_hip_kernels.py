@@ -419,6 +419,53 @@ def test_decoder_attention(capi, B, T, P, heads, dtype):
     assert_close(stats[..., 1], (s - s.max(dim=1, keepdim=True).values).exp().sum(dim=1), 1e-4, 1e-4, "sumexp")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("modes", [0, 3])
+def test_decoder_attention_reads_keys_and_values_in_place(capi, dtype, modes):
+    """dfd_kv_layout_t: keys / values read straight out of a q|k|v activation [frames, tokens, 3D] (CLS row skipped,
+    row stride 3D) with the temporal positional embedding added on the fly must give, bit for bit, what the dense
+    f32 export (k + pos) gives: forward mix / stats, attn_mode scores and weights, backward dq / dpos."""
+    B, T, P, H = 3, 4, 20, 4
+    D, tok, S = H * 64, P + 1, T * P
+    qkv = rnd(B * T, tok, 3 * D, seed=51).to(dtype).cuda()
+    pos = rnd(T, D, seed=52, scale=0.3).cuda()
+    kview, vview = qkv[:, 1:, D:2 * D], qkv[:, 1:, 2 * D:]
+    pb = pos.repeat(B, 1).view(B * T, 1, D)
+    kd, vd = (kview.float() + pb).contiguous().view(B * S, D), (vview.float() + pb).contiguous().view(B * S, D)
+    q = rnd(B, 2 * D, seed=53).cuda()
+    m = torch.ones(B, T, dtype=torch.uint8)
+    m[1, T - 1:] = 0
+    m = m.cuda()
+    dmix = rnd(B, D, seed=54).cuda()
+    splits = 2
+    f32 = dict(device="cuda", dtype=torch.float32)
+
+    def run(k, v, p):
+        ws = torch.empty(capi.decoder_attn_workspace_bytes(B, H, 64, splits) // 4, **f32)
+        mix, mix_s, stats = torch.empty(B, D, **f32), torch.empty(B, D, **f32), torch.empty(B, H, 2, **f32)
+        sc = aw = dsc = None
+        if modes:
+            sc, aw, dsc = torch.empty(B, H, S, **f32), torch.empty(B, H, S, **f32), torch.empty(B, H, S, **f32)
+            capi.decoder_attn_modes_fwd(q, k, m, modes, sc, aw, B, T, P, H, pos=p)
+        capi.decoder_attn_fwd(q, k, v, m, mix, stats, ws, splits, B, T, P, H, mix_softmax=mix_s, ext_weights=aw, pos=p)
+        if modes:
+            capi.decoder_attn_modes_bwd(sc, v, dmix, modes, torch.empty(B, H, S, **f32), dsc, B, T, P, H, pos=p)
+        ws2 = torch.empty(capi.decoder_attn_bwd_workspace_bytes(B, T, H) // 4, **f32)
+        dq, dpos = torch.empty(B, 2 * D, **f32), torch.empty(T, D, **f32)
+        capi.decoder_attn_bwd(q, k, v, m, dmix, None if modes else mix_s, None if modes else stats, dq, dpos, ws2, B, T, P, H,
+                              ext_weights=aw, ext_dscores=dsc, pos=p)
+        return [t for t in (mix, None if modes else stats, sc, aw, dq, dpos) if t is not None]
+
+    bits = lambda t: t.view(torch.int32)  # bitwise: a fully padded frame's "frame" softmax is NaN on both sides
+    got, want = run(kview, vview, pos), run(kd, vd, None)
+    for a, b in zip(got, want):
+        assert torch.equal(bits(a), bits(b))
+    # a dense tensor with `pos` given takes the same path
+    got2 = run(kview.contiguous().view(B * S, D), vview.contiguous().view(B * S, D), pos)
+    for a, b in zip(got2, want):
+        assert torch.equal(bits(a), bits(b))
+
+
 @pytest.mark.parametrize("B,N,K", [(1, 8, 128), (2, 256, 128), (16, 1536, 768), (16, 768, 3072), (9, 100, 64)])
 def test_linear_rows(capi, B, N, K):
     x, w, b = rnd(B, K, seed=20), rnd(N, K, seed=21, scale=K ** -0.5), rnd(N, seed=22, scale=0.1)
