@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--frame-chunk", type=int, default=-1, help="frames per encoder pass (-1 = package default)")
     ap.add_argument("--streams", type=int, default=-1, help="HIP streams for independent frame chunks (-1 = package default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kv-export", action="store_true",
+                    help="A/B: let the projection's epilogue export K/V + positional embedding (round 1's hand-over) instead of the "
+                         "decoder reading them in place")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the informational ViT-L/14 lines (BASELINE configs[3] bf16 / configs[4] fp8) of the default single-GPU run")
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
@@ -95,6 +98,8 @@ def build_model(args, device):
         det.encoder.frame_chunk = args.frame_chunk
     if args.streams >= 0:
         det.encoder.streams = args.streams
+    if args.kv_export:
+        det.kv_in_place = False
     if args.spare_cus >= 0:
         det.pipeline_spare_cus = args.spare_cus
     if args.spare_layers >= 0:
