@@ -15,50 +15,22 @@
 //   row once per 8 clips; x stays L1/L2 resident.
 // dfd_head_fwd — ln_post + projection + 5·z/(‖z‖+1e-10).
 #include "dropout.hpp"
+#include "decoder_common.hpp"
 
 namespace {
 
 constexpr int HD = 64;
 constexpr int PART = 2 + 2 * HD;  // floats per (clip, split, head): m, l, acc_s[64], acc_c[64]
 
-template <typename T> struct Ld8;
-template <> struct Ld8<float> {
-  static __device__ __forceinline__ void load(const float* p, float* o) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
-  }
-};
-template <> struct Ld8<bf16_t> {
-  static __device__ __forceinline__ void load(const bf16_t* p, float* o) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (float)a[e];
-  }
-};
-
-__device__ __forceinline__ float group8_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  return v;
-}
-
-__device__ __forceinline__ float fast_tanh(float x) {
-  // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, abs error ~1e-7 around 0
-  const float e = __expf(2.0f * x);
-  return 1.0f - 2.0f / (e + 1.0f);
-}
-
-template <typename T, int MAXT>
-__global__ __launch_bounds__(MAXT) void decoder_attn_partial_kernel(const float* __restrict__ q, const T* __restrict__ k,
+template <typename T, int MAXT, bool POS>
+__global__ __launch_bounds__(MAXT, (MAXT <= 512 ? 3 : 4)) void decoder_attn_partial_kernel(const float* __restrict__ q, const T* __restrict__ k,
                                                                     const T* __restrict__ v,
                                                                     const uint8_t* __restrict__ frame_mask,
                                                                     const float* __restrict__ ext_w,
                                                                     float* __restrict__ ws, int splits, int T_frames,
                                                                     int patches, int heads, int R, KvLayout lay,
                                                                     FastDiv div_patches) {
-  extern __shared__ float red[];  // [R][tpr][18]
+  extern __shared__ float red[];  // [R][tpr][18], then (POS) the positional embedding of this block's frames
   const int tpr = heads * 8;
   const int b = blockIdx.y, split = blockIdx.x;
   const int rs = threadIdx.x / tpr, tr = threadIdx.x % tpr;
@@ -68,6 +40,17 @@ __global__ __launch_bounds__(MAXT) void decoder_attn_partial_kernel(const float*
   const int per = (S + splits - 1) / splits;
   const int s_begin = split * per;
   const int s_end = min(S, s_begin + per);
+  // POS: the rows of this block lie in frames f0 .. f1 of the clip; their positional embeddings are staged in LDS
+  // once (held in registers they cost the kernel half its occupancy)
+  [[maybe_unused]] float* const posl = red + (size_t)blockDim.x * 18;
+  [[maybe_unused]] const int f0 = (int)div_patches.div((uint32_t)min(s_begin, S - 1));
+  if constexpr (POS) {
+    const int f1 = (int)div_patches.div((uint32_t)(max(s_end, s_begin + 1) - 1 < S ? max(s_end, s_begin + 1) - 1 : S - 1));
+    const int n4 = (f1 - f0 + 1) * (D >> 2);
+    for (int i = threadIdx.x; i < n4; i += blockDim.x)
+      reinterpret_cast<f32x4*>(posl)[i] = reinterpret_cast<const f32x4*>(lay.pos + (int64_t)f0 * D)[i];
+    __syncthreads();
+  }
 
   float qs[8], qc[8];
   {
@@ -85,72 +68,81 @@ __global__ __launch_bounds__(MAXT) void decoder_attn_partial_kernel(const float*
   // row s of clip b = patch (s % patches) of frame b*T + s / patches (KvLayout: dense export or the qkv activation in place)
   const T* kb = k + (int64_t)b * T_frames * lay.frame_stride + hd * HD + sub * 8;
   const T* vb = v + (int64_t)b * T_frames * lay.frame_stride + hd * HD + sub * 8;
-  const float* pb = lay.pos ? lay.pos + hd * HD + sub * 8 : nullptr;
+  [[maybe_unused]] const float* const pb = posl + hd * HD + sub * 8;
   const uint8_t* mb = frame_mask + (int64_t)b * T_frames;
-  // every lane of an 8-lane group walks the same rows, so the shuffles below are convergent.
-  // Rows are taken four at a time with all eight loads issued before the first use: the loop is a
-  // latency chain otherwise (a dozen dependent HBM round trips per thread).
-  constexpr int UN = 4;
+  const int lane_base = (threadIdx.x & 63) & ~7;
+  // Eight rows per trip, one per lane of the 8-lane head group, all sixteen loads issued before the first use (the
+  // loop is a latency chain otherwise).  Every lane forms its 8-channel share of the three dot products of all eight
+  // rows; a reduce-scatter over the group leaves lane j with the totals of row j, so the row's transcendentals
+  // (exp, tanh, sigmoid: the VALU bulk of this kernel) run ONCE per row instead of once per lane; the row weights
+  // then travel back to the group for the V accumulation.  The softmax is rescaled once per trip.
+  constexpr int UN = 8;
+  float l_own = 0.f;  // softmax weights of the rows this lane finished; summed over the group at the end
   for (int s0 = s_begin + rs; s0 < s_end; s0 += UN * R) {
-    float kk[UN][8], vv[UN][8];
-    int tf[UN];
+    Raw8<T> kr[UN], vr[UN];
+    [[maybe_unused]] int po[UN];  // LDS offset of the row's frame in the staged positional embeddings
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int s = min(s0 + u * R, S - 1);  // clamp: rows past the end are loaded but not used
-      tf[u] = (int)div_patches.div((uint32_t)s);
-      const int64_t off = (int64_t)tf[u] * lay.frame_stride + (int64_t)(s - tf[u] * patches) * lay.row_stride;
-      Ld8<T>::load(kb + off, kk[u]);
-      Ld8<T>::load(vb + off, vv[u]);
+      const int s = min(min(s0 + u * R, s_end - 1), S - 1);  // clamp: rows past the end are loaded but not used
+      const int tf = (int)div_patches.div((uint32_t)s);
+      const int64_t off = (int64_t)tf * lay.frame_stride + (int64_t)(s - tf * patches) * lay.row_stride;
+      kr[u].load(kb + off);
+      vr[u].load(vb + off);
+      po[u] = (tf - f0) * D;
     }
-    if (pb != nullptr) {  // temporal positional embedding of the row's frame, added to the key and the value
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        float pe[8];
-        Ld8<float>::load(pb + (int64_t)tf[u] * D, pe);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { kk[u][e] += pe[e]; vv[u][e] += pe[e]; }
-      }
-    }
+    float pds[UN], pdc[UN], pl1[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int s = s0 + u * R;
-      if (s >= s_end) break;  // uniform within the 8-lane group (and the wave's other groups only skip work)
       float ds = 0.f, dc = 0.f, l1 = 0.f;
+      [[maybe_unused]] float pe[8];
+      if constexpr (POS) Ld8<float>::load(pb + po[u], pe);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        ds = fmaf(qs[e], kk[u][e], ds);
-        dc = fmaf(qc[e] * 0.125f, kk[u][e], dc);
-        l1 += fabsf(qc[e] - kk[u][e]);
+        const float kk = POS ? kr[u].get(e) + pe[e] : kr[u].get(e);
+        ds = fmaf(qs[e], kk, ds);
+        dc = fmaf(qc[e] * 0.125f, kk, dc);
+        l1 += fabsf(qc[e] - kk);
       }
-      ds = group8_sum(ds);
-      dc = group8_sum(dc);
-      l1 = group8_sum(l1);
-      if (mb[tf[u]]) {
-        float p;
-        if (ext_w != nullptr) {
-          // attn_mode: the softmax-branch weight was computed by the grouped-softmax pass
-          p = ext_w[((int64_t)b * heads + hd) * S + s];
-        } else {
-          if (ds > mx) {
-            const float alpha = __expf(mx - ds);
-            l *= alpha;
+      pds[u] = ds;
+      pdc[u] = dc;
+      pl1[u] = l1;
+    }
+    const float ds = group8_reduce_scatter(pds, sub), dc = group8_reduce_scatter(pdc, sub), l1 = group8_reduce_scatter(pl1, sub);
+    // my row of this trip
+    const int s_me = s0 + sub * R;
+    const bool ok = s_me < s_end && mb[div_patches.div((uint32_t)min(s_me, S - 1))] != 0;
+    float p;
+    if (ext_w != nullptr) {
+      // attn_mode: the softmax-branch weight was computed by the grouped-softmax pass
+      p = ok ? ext_w[((int64_t)b * heads + hd) * S + s_me] : 0.f;
+    } else {
+      const float m_new = fmaxf(mx, group8_max(ok ? ds : -INFINITY));
+      if (m_new != mx) {  // uniform over the group; exp(-inf) = 0 the first time
+        const float alpha = __expf(mx - m_new);
+        l_own *= alpha;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) as[e] *= alpha;
-            mx = ds;
-          }
-          p = __expf(ds - mx);
-          l += p;
-        }
-        const float gate = 2.0f / (1.0f + __expf(l1 * 0.125f));  // 2·sigmoid(−l1/√d)
-        const float c = fast_tanh(dc) * gate;
+        for (int e = 0; e < 8; ++e) as[e] *= alpha;
+        mx = m_new;
+      }
+      p = ok ? __expf(ds - mx) : 0.f;
+      l_own += p;
+    }
+    const float gate = 2.0f / (1.0f + __expf(l1 * 0.125f));  // 2·sigmoid(−l1/√d)
+    const float c = ok ? fast_tanh(dc) * gate : 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          as[e] = fmaf(p, vv[u][e], as[e]);
-          ac[e] = fmaf(c, vv[u][e], ac[e]);
-        }
+    for (int u = 0; u < UN; ++u) {
+      const float pu = __shfl(p, lane_base + u, 64), cu = __shfl(c, lane_base + u, 64);
+      [[maybe_unused]] float pe[8];
+      if constexpr (POS) Ld8<float>::load(pb + po[u], pe);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float vv = POS ? vr[u].get(e) + pe[e] : vr[u].get(e);
+        as[e] = fmaf(pu, vv, as[e]);
+        ac[e] = fmaf(cu, vv, ac[e]);
       }
     }
   }
+  l = group8_sum(l_own);
   if (ext_w != nullptr) {  // weights are final: neutral softmax state, unit normaliser counted once
     mx = 0.f;
     l = (split == 0 && rs == 0) ? 1.f : 0.f;
@@ -530,16 +522,29 @@ extern "C" int dfd_decoder_attn_fwd(const float* q, const void* k, const void* v
   const int R = rows_per_block(heads);
   const int threads = heads * 8 * R;
   DFD_REQUIRE(threads <= 1024, "dfd_decoder_attn_fwd: heads=%d needs %d threads", heads, threads);
-  const size_t lds = (size_t)threads * 18 * sizeof(float);
+  const int S_ = T * patches, per_ = (S_ + splits - 1) / splits;
+  const int span = lay.pos ? (per_ + patches - 2) / patches + 1 : 0;  // frames a block's rows can touch
+  const size_t lds = (size_t)threads * 18 * sizeof(float) + (size_t)(span < T ? span : T) * heads * HD * sizeof(float);
+  DFD_REQUIRE(lds <= 160 * 1024, "dfd_decoder_attn_fwd: %zu B of LDS (use more splits)", lds);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(splits, B), block(threads);
   float* ws = static_cast<float*>(workspace);
-#define PARTIAL_LAUNCH(KT, MT)                                                                                      \
-  hipLaunchKernelGGL((decoder_attn_partial_kernel<KT, MT>), grid, block, lds, st, q, static_cast<const KT*>(k),     \
-                     static_cast<const KT*>(v), frame_mask, ext_weights, ws, splits, T, patches, heads, R, lay, divp)
+#define PARTIAL_LAUNCH1(KT, MT, PS)                                                                                  \
+  do {                                                                                                               \
+    if (lds > 64 * 1024)                                                                                             \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decoder_attn_partial_kernel<KT, MT, PS>),              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+    hipLaunchKernelGGL((decoder_attn_partial_kernel<KT, MT, PS>), grid, block, lds, st, q, static_cast<const KT*>(k), \
+                       static_cast<const KT*>(v), frame_mask, ext_weights, ws, splits, T, patches, heads, R, lay, divp); \
+  } while (0)
+#define PARTIAL_LAUNCH(KT, MT)                                                                                       \
+  do {                                                                                                               \
+    if (lay.pos) PARTIAL_LAUNCH1(KT, MT, true); else PARTIAL_LAUNCH1(KT, MT, false);                                 \
+  } while (0)
   if (kv_dtype == DFD_F32) { if (threads <= 512) PARTIAL_LAUNCH(float, 512); else PARTIAL_LAUNCH(float, 1024); }
   else { if (threads <= 512) PARTIAL_LAUNCH(bf16_t, 512); else PARTIAL_LAUNCH(bf16_t, 1024); }
 #undef PARTIAL_LAUNCH
+#undef PARTIAL_LAUNCH1
   DFD_CHECK_LAUNCH("dfd_decoder_attn_fwd(partial)");
   hipLaunchKernelGGL(decoder_attn_combine_kernel, dim3(B), dim3(heads * HD), (size_t)heads * splits * sizeof(float), st, ws, mix,
                      mix_softmax, stats, splits, heads);

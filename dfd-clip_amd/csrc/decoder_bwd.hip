@@ -11,33 +11,12 @@
 // dfd_linear_rows_bwd_weight, dfd_transpose_f32, dfd_layernorm_bwd, dfd_quickgelu, dfd_head_bwd —
 //   the [B, D]-row pieces of the backward.
 #include "dropout.hpp"
+#include "decoder_common.hpp"
 
 namespace {
 
 constexpr int HD = 64;
 
-template <typename T> struct Ld8;
-template <> struct Ld8<float> {
-  static __device__ __forceinline__ void load(const float* p, float* o) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
-  }
-};
-template <> struct Ld8<bf16_t> {
-  static __device__ __forceinline__ void load(const bf16_t* p, float* o) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (float)a[e];
-  }
-};
-
-__device__ __forceinline__ float group8_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  return v;
-}
 __device__ __forceinline__ float sgn(float x) { return (float)(x > 0.f) - (float)(x < 0.f); }
 
 // grid (T, B).  part layout per (b, t): [heads][128] dq (softmax query | CoDA query), then [heads*64] dpos.
@@ -97,66 +76,84 @@ __global__ __launch_bounds__(MAXT) void decoder_attn_bwd_kernel(const float* __r
 #pragma unroll
     for (int e = 0; e < 8; ++e) pe[e] = 0.f;
     if (lay.pos != nullptr) Ld8<float>::load(lay.pos + (int64_t)t * D + hd * HD + sub * 8, pe);
-    // two rows per trip, all four loads issued before the first use (the trip is a latency chain otherwise)
-    constexpr int UN = 2;
+    // Four rows per trip, all eight loads issued before the first use (the trip is a latency chain otherwise).
+    // Every lane forms its 8-channel share of the four dot products of the four rows; a reduce-scatter over the
+    // 8-lane head group leaves lanes j and j+4 with the totals of row j, so a row's transcendentals and divisions
+    // (the VALU bulk here) run on two lanes instead of eight; its three gradient scalars travel back to the group
+    // for the per-channel accumulation.
+    constexpr int UN = 4;
+    const int lane_base = (threadIdx.x & 63) & ~7;
+    float a1o = 0.f, a2o = 0.f, a3o = 0.f;  // sums over the rows lanes 0..3 of the group finished
     for (int j0 = rs; j0 < patches; j0 += UN * R) {
-      float kq[UN][8], vq[UN][8];
+      Raw8<T> kq[UN], vq[UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
         const int j = min(j0 + u * R, patches - 1);
-        Ld8<T>::load(kb + (int64_t)j * lay.row_stride, kq[u]);
-        Ld8<T>::load(vb + (int64_t)j * lay.row_stride, vq[u]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { kq[u][e] += pe[e]; vq[u][e] += pe[e]; }
+        kq[u].load(kb + (int64_t)j * lay.row_stride);
+        vq[u].load(vb + (int64_t)j * lay.row_stride);
       }
+      float ps[UN], pt[UN], pl[UN], pw[UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
-        const int j = j0 + u * R;
-        if (j >= patches) break;
-        const float* kk = kq[u];
-        const float* vv = vq[u];
         float s = 0.f, tt = 0.f, l1 = 0.f, dw = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          s = fmaf(qs[e] * 0.125f, kk[e], s);
-          tt = fmaf(qc[e] * 0.125f, kk[e], tt);
-          l1 += fabsf(qc[e] - kk[e]);
-          dw = fmaf(dm[e], vv[e], dw);
+          const float kk = kq[u].get(e) + pe[e], vv = vq[u].get(e) + pe[e];
+          s = fmaf(qs[e] * 0.125f, kk, s);
+          tt = fmaf(qc[e] * 0.125f, kk, tt);
+          l1 += fabsf(qc[e] - kk);
+          dw = fmaf(dm[e], vv, dw);
         }
-        s = group8_sum(s);
-        tt = group8_sum(tt);
-        l1 = group8_sum(l1);
-        dw = group8_sum(dw);
-        const int64_t wi = ((int64_t)b * heads + hd) * S + s0 + j;
-        const float aw = ext ? ext_w[wi] : __expf(s - M) * invL;      // softmax(-branch) weight
-        const float g = 2.0f / (1.0f + __expf(l1 * 0.125f));         // 2·sigmoid(−l1/8)
-        const float e2 = __expf(2.0f * tt);
-        const float th = 1.0f - 2.0f / (e2 + 1.0f);                  // tanh
-        const float w = 0.5f * (aw + th * g);
-        const float ds = ext ? ext_ds[wi] : aw * (0.5f * dw - dlt);
-        const float dc = 0.5f * dw;
-        const float dt = dc * g * (1.0f - th * th);
-        const float dL = -(dc * th) * g * (1.0f - 0.5f * g) * 0.125f;
-        a1 += ds;
-        a2 += dt;
-        a3 += w;
+        ps[u] = s; pt[u] = tt; pl[u] = l1; pw[u] = dw;
+      }
+      const float s = group8_reduce_scatter4(ps, sub), tt = group8_reduce_scatter4(pt, sub);
+      const float l1 = group8_reduce_scatter4(pl, sub), dw = group8_reduce_scatter4(pw, sub);
+      // my row of this trip (shared with lane sub ^ 4)
+      const int jm = j0 + (sub & 3) * R;
+      const bool ok = jm < patches;
+      const int64_t wi = ((int64_t)b * heads + hd) * S + s0 + min(jm, patches - 1);
+      const float aw = ext ? ext_w[wi] : __expf(s - M) * invL;      // softmax(-branch) weight
+      const float g = 2.0f / (1.0f + __expf(l1 * 0.125f));         // 2·sigmoid(−l1/8)
+      const float e2 = __expf(2.0f * tt);
+      const float th = 1.0f - 2.0f / (e2 + 1.0f);                  // tanh
+      const float w = ok ? 0.5f * (aw + th * g) : 0.f;
+      const float dc = 0.5f * dw;
+      const float ds = ok ? (ext ? ext_ds[wi] : aw * (0.5f * dw - dlt)) : 0.f;
+      const float dt = ok ? dc * g * (1.0f - th * th) : 0.f;
+      const float dL = ok ? -(dc * th) * g * (1.0f - 0.5f * g) * 0.125f : 0.f;
+      if (sub < 4) {  // each row once
+        a1o += ds;
+        a2o += dt;
+        a3o += w;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const float dsu = __shfl(ds, lane_base + u, 64), dtu = __shfl(dt, lane_base + u, 64), dLu = __shfl(dL, lane_base + u, 64);
         float dkk[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float sg = sgn(qc[e] - kk[e]) * dL;
-          dqs[e] = fmaf(ds * 0.125f, kk[e], dqs[e]);
-          dqc[e] = fmaf(dt * 0.125f, kk[e], dqc[e]) + sg;
+          const float kk = kq[u].get(e) + pe[e];
+          const float sg = sgn(qc[e] - kk) * dLu;
+          dqs[e] = fmaf(dsu * 0.125f, kk, dqs[e]);
+          dqc[e] = fmaf(dtu * 0.125f, kk, dqc[e]) + sg;
           sv[e] += sg;
-          dkk[e] = (ds * qs[e] + dt * qc[e]) * 0.125f - sg;
+          dkk[e] = (dsu * qs[e] + dtu * qc[e]) * 0.125f - sg;
         }
         if (dk_out != nullptr) {
-          G* ko = dk_out + ((int64_t)b * S + s0 + j) * D + hd * HD + sub * 8;
-          G* vo = dv_out + ((int64_t)b * S + s0 + j) * D + hd * HD + sub * 8;
+          const float wu = __shfl(w, lane_base + u, 64);
+          const int j = j0 + u * R;
+          if (j < patches) {
+            G* ko = dk_out + ((int64_t)b * S + s0 + j) * D + hd * HD + sub * 8;
+            G* vo = dv_out + ((int64_t)b * S + s0 + j) * D + hd * HD + sub * 8;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { ko[e] = from_f32<G>(dkk[e]); vo[e] = from_f32<G>(w * dm[e]); }
+            for (int e = 0; e < 8; ++e) { ko[e] = from_f32<G>(dkk[e]); vo[e] = from_f32<G>(wu * dm[e]); }
+          }
         }
       }
     }
+    a1 = group8_sum(a1o);
+    a2 = group8_sum(a2o);
+    a3 = group8_sum(a3o);
   } else if (dk_out != nullptr) {
     for (int j = rs; j < patches; j += R) {
       G* ko = dk_out + ((int64_t)b * S + t * patches + j) * D + hd * HD + sub * 8;
