@@ -330,13 +330,15 @@ def main():
                                     f"BASELINE configs[1]: {args.arch} forward-only Detector.predict (inference.py path)")
                                    + f", {B} clips x {T} frames x 3x{res}x{res} per GPU, decode layers {det.layer_indices}, "
                                      f"random-init weights, inputs resident in HBM",
-                       "mode": args.mode, "adapter": args.adapter, "clips_per_gpu": B, "frames_per_clip": T, "hip_graphs": bool(det.static_graphs), "pipelined_encoder": bool(det.pipeline_encoder), "frame_chunk": det.encoder.frame_chunk,
+                       "mode": args.mode, "adapter": args.adapter, "clips_per_gpu": B, "frames_per_clip": T, "hip_graphs": bool(det.static_graphs) and not det.decoder._graphs_failed, "pipelined_encoder": bool(det.pipeline_encoder), "frame_chunk": det.encoder.frame_chunk,
                        "streams": det.encoder.streams},
             "roofline": {"bound": "mfma", "kernel": "c_fc GEMM + QuickGELU (M=%d, N=%d, K=%d)" % (launch_m, 4 * width, width),
                          "achieved": round(achieved, 2) if achieved else None, "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,
                          "launches_timed": len(spans), "avg_launch_ms": round(avg_ms, 4)},
         }
+        if det.decoder._graphs_failed and not graph_note:
+            graph_note = "HIP graph capture refused by the runtime, decoder on eager launches: " + det.decoder._graphs_failed[:160]
         if graph_note:
             line["config"]["note"] = graph_note
         if fwd_only is not None:

@@ -15,6 +15,8 @@ Kernel sequence per block, rows = clips (B), everything f32 except the K/V strea
 """
 import weakref
 
+import logging
+
 import torch
 from torch import nn
 
@@ -55,7 +57,7 @@ class DecoderTransformer(_Holder):
 
 
 class Decoder(RuntimeStateMixin, nn.Module):
-    _RUNTIME_STATE = {"_wt_cache": {}, "_after_backward": None, "_param_list": None}
+    _RUNTIME_STATE = {"_wt_cache": {}, "_after_backward": None, "_param_list": None, "_graphs_failed": None}
 
     def invalidate_caches(self):
         """After parameters were rewritten in place behind autograd's back."""
@@ -103,6 +105,7 @@ class Decoder(RuntimeStateMixin, nn.Module):
         # so the host enqueues a step in a few milliseconds however loaded its cores are.  Needs K/V at
         # stable addresses (Detector keeps persistent export buffers in this mode).
         self.use_graphs = False
+        self._graphs_failed = None  # set when the runtime refused a capture: eager launches from then on
         self._after_backward = None  # one-shot callback for the next autograd node (Detector's encoder pipelining)
         # decoder blocks start from the encoder layer they read (models.py:226-229)
         for b, l in enumerate(self.layer_indices):
@@ -466,6 +469,8 @@ class Decoder(RuntimeStateMixin, nn.Module):
 
     def _graph_forward(self, w, k_all, v_all, mask, dims, params, drop_rng=None, kv_pos=None):
         B, T, P = dims
+        if self._graphs_failed:
+            return None
         key = self._graph_key(k_all, v_all, mask, dims, params, drop_rng is not None, kv_pos)
         graphs = _GRAPHS.setdefault(self, {})
         ent = graphs.get(key)
@@ -478,9 +483,17 @@ class Decoder(RuntimeStateMixin, nn.Module):
             self._forward_kernels(w, k_all, v_all, ent["mask"], B, T, P, save=True, drop_rng=ent["rng"], kv_pos=kv_pos)  # eager once: lazy initialisations
             self._wt_cache.clear()  # the weight transposes must be nodes of the graph (weights change every step)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                raws, feat, outs, saved = self._forward_kernels(w, k_all, v_all, ent["mask"], B, T, P, save=True, drop_rng=ent["rng"], kv_pos=kv_pos)
+            try:
+                # thread_local: other threads of the process (the RCCL watchdog, a data loader) may keep calling into
+                # the runtime while this thread captures
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    raws, feat, outs, saved = self._forward_kernels(w, k_all, v_all, ent["mask"], B, T, P, save=True, drop_rng=ent["rng"], kv_pos=kv_pos)
+            except Exception as e:  # capture is an optimisation: a runtime that refuses it leaves the eager launches
+                self._graphs_failed = f"{type(e).__name__}: {e}"
+                logging.warning("decoder: HIP graph capture failed, staying on eager launches (%s)", self._graphs_failed)
+                torch.cuda.synchronize()
+                return None
             ent.update(fwd=g, raws=raws, feat=feat, outs=outs, saved=saved)
             graphs[key] = ent
         ent["mask"].copy_(mask)
@@ -500,10 +513,16 @@ class Decoder(RuntimeStateMixin, nn.Module):
             self._backward_kernels(w, ent["saved"], k_all, v_all, ent["mask"], B, T, P, b["d_feat"], b["d_raws"], b["d_logits"],
                                    want_dkv)  # eager once
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                grads = self._backward_kernels(w, ent["saved"], k_all, v_all, ent["mask"], B, T, P, b["d_feat"], b["d_raws"],
-                                               b["d_logits"], want_dkv)
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    grads = self._backward_kernels(w, ent["saved"], k_all, v_all, ent["mask"], B, T, P, b["d_feat"], b["d_raws"],
+                                                   b["d_logits"], want_dkv)
+            except Exception as e:  # as in the forward: fall back to the eager kernels on the forward graph's saved tensors
+                self._graphs_failed = f"{type(e).__name__}: {e}"
+                logging.warning("decoder: HIP graph capture of the backward failed, staying on eager launches (%s)", self._graphs_failed)
+                torch.cuda.synchronize()
+                return self._backward_kernels(w, ent["saved"], k_all, v_all, ent["mask"], B, T, P, d_feat, d_raws, d_logits, want_dkv)
             b.update(graph=g, grads=grads)
             ent["bwd"][sig] = b
         if d_feat is not None:
