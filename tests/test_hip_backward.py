@@ -410,8 +410,11 @@ def test_pipelined_encoder_matches_eager_training(graphs, name):
         assert torch.equal(det_p(x, [y], m, single_task=0)[1][0], det_e.eval()(x, [y], m, single_task=0)[1][0])
 
 
-def test_pipelined_encoder_full_size_trainable_positional_embedding():
-    """the pipelined encoder stream must not read the TRAINABLE temporal positional embedding
+@pytest.mark.parametrize("kv_in_place", [True, False])
+def test_pipelined_encoder_full_size_trainable_positional_embedding(kv_in_place):
+    """kv_in_place: the default hand-over (the decoder reads K/V and the live positional embedding on the caller's
+    stream) and the export path (the projection's epilogue adds a snapshot of it on the encoder stream).
+    ADVICE r1 (high): the pipelined encoder stream must not read the TRAINABLE temporal positional embedding
     while the previous step's optimizer is writing it.  Full size (ViT-B/16, 16 clips x 30 frames, bf16), large
     learning rate on the positional embedding, six back-to-back steps with NO host synchronisation (the host runs
     several steps ahead of the device, as in bench.py), graphs + pipelining + inputs_ready — against the plain
@@ -425,6 +428,7 @@ def test_pipelined_encoder_full_size_trainable_positional_embedding():
     det_e = Detector(cfg, T, None, precision="bf16")
     det_e.load_state_dict(random_state_dict(cfg, T, seed=0))
     det_e = det_e.cuda().train()
+    det_e.kv_in_place = kv_in_place
     det_p = copy.deepcopy(det_e)
     det_p.pipeline_encoder, det_p.inputs_ready, det_p.static_graphs = True, True, True
     g = torch.Generator(device="cuda").manual_seed(5)
