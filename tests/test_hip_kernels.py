@@ -354,7 +354,7 @@ def test_gemm_qkv_export_layout(capi, dtype):
 
 
 @pytest.mark.parametrize("n,tokens,heads", [(2, 5, 2), (3, 197, 4), (1, 257, 2), (2, 50, 12), (64, 197, 12), (45, 200, 12),
-                                            (43, 205, 12), (48, 210, 12)])
+                                            (43, 205, 12), (48, 210, 12), (33, 257, 16), (47, 230, 12)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_encoder_attention(capi, n, tokens, heads, dtype):
     D = heads * 64
@@ -372,17 +372,18 @@ def test_encoder_attention(capi, n, tokens, heads, dtype):
         assert_close(out, want, 2e-2, 2 ** -7, "attention bf16")
 
 
-@pytest.mark.parametrize("n,tokens", [(64, 197), (45, 200), (43, 205)])
-def test_encoder_attention_persistent_kernel_matches_per_item_kernel(capi, n, tokens):
-    """>= 512 (frame, head) items take the persistent kernel (loader wave + LDS-DMA, two barriers per item); the same
-    frames in chunks below that threshold take the one-workgroup-per-item kernel: same arithmetic, same bits."""
-    heads, D = 12, 768
+@pytest.mark.parametrize("n,tokens,heads", [(64, 197, 12), (45, 200, 12), (43, 205, 12), (40, 257, 16), (45, 288, 12), (50, 226, 12)])
+def test_encoder_attention_persistent_kernel_matches_per_item_kernel(capi, n, tokens, heads):
+    """>= 512 (frame, head) items of 193..208 tokens take the persistent kernel (loader wave + LDS-DMA, two barriers
+    per item); the same frames in chunks below that threshold — and every other token count — take the
+    one-workgroup-per-item kernel: same arithmetic, same bits, whatever the launch geometry."""
+    D = heads * 64
     qkv = rnd(n * tokens, 3 * D, seed=23).to(torch.bfloat16).cuda()
     qkv[:, :D] *= 2.0
     whole = torch.empty(n * tokens, D, device="cuda", dtype=torch.bfloat16)
     capi.attention_fwd(qkv, whole, n, tokens, heads)
     parts = torch.empty_like(whole)
-    step = 16  # 192 items per call
+    step = 16  # at most 256 items per call
     for f0 in range(0, n, step):
         f1 = min(n, f0 + step)
         capi.attention_fwd(qkv[f0 * tokens:f1 * tokens], parts[f0 * tokens:f1 * tokens], f1 - f0, tokens, heads)
