@@ -237,6 +237,27 @@ def test_frame_chunking_is_bit_identical():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+def test_frame_chunking_in_place_is_bit_identical():
+    """The in-place hand-over (tapped layers keep their q|k|v activation) with the batch cut into per-clip chunks, on
+    one stream and round-robin on two: the same buffer contents, hence the same logits, as the single pass."""
+    case = build_case("small")
+    det = make_detector(case, "bf16")
+    x, m = case["x"].cuda(), case["m"].cuda()
+    n, tok, D, L = x.shape[0] * case["T"], det.encoder.tokens, det.encoder.width, len(case["layer_indices"])
+    outs = []
+    for chunk, streams in ((0, 1), (case["T"], 1), (case["T"], 2)):
+        det.encoder.frame_chunk, det.encoder.streams = chunk, streams
+        buf = torch.zeros(L, n, tok, 3 * D, device="cuda", dtype=det.encoder.act_dtype)
+        k, v = det.encoder.extract_kv(x.flatten(0, 1), case["layer_indices"], case["T"], in_place=buf)
+        assert k.shape == (L, n, tok - 1, D) and k.data_ptr() == buf[:, :, 1:, D:2 * D].data_ptr()
+        with torch.no_grad():
+            logits = det.predict(x, m)[0][0]
+        torch.cuda.synchronize()
+        outs.append((k.clone(), v.clone(), logits.clone()))
+    for k, v, lg in outs[1:]:
+        assert torch.equal(k, outs[0][0]) and torch.equal(v, outs[0][1]) and torch.equal(lg, outs[0][2])
+
+
 def test_num_frames_mismatch_raises():
     case = build_case("tiny")
     det = make_detector(case, "fp32")
