@@ -1,3 +1,5 @@
+// LAB ONLY: dfd-clip_amd/csrc/attention_mfma.hip with in-kernel s_memtime stamps (build: tools/lab/build_attn_stamps.sh;
+// read: tools/lab/attn_stamps_persist.py).  The product source carries no instrumentation; keep the two in step by hand.
 // bf16 MFMA self-attention for the encoder: out = softmax(q kᵀ · scale) v per (frame, head),
 // head_dim 64, tokens <= 32*NB (197 -> NB = 7, 257 -> NB = 9) (reference clip/model.py:188-195).
 //
@@ -15,11 +17,30 @@
 //     second product Oᵀ = Vᵀ·Pᵀ (accumulator-as-operand, k order permuted the same way on the
 //     Vt fragment), so P never touches LDS; a lane ends with 4 consecutive output channels of
 //     its query per register group and stores them as 8-byte pieces.
-#include "common.hpp"
+#include "../../dfd-clip_amd/csrc/common.hpp"
+
+#ifndef ATTN_STAMPS
+#define ATTN_STAMPS 1  // diagnostic build: wave 0 of each workgroup writes cycle stamps to `out`-adjacent debug memory
+#endif
 
 namespace {
 
 constexpr int HD = 64;
+#if ATTN_STAMPS
+__device__ float* g_attn_dbg = nullptr;
+__device__ __forceinline__ unsigned long long astamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define ASTAMP(v) const unsigned long long v = astamp()
+#define PSTAMP(v) const unsigned long long v = astamp()
+#else
+#define ASTAMP(v)
+#define PSTAMP(v)
+#endif
 
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
@@ -56,6 +77,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const bf16_t* __restr
   // only two workgroups per CU, serialising load -> write per iteration exposes NB HBM latencies.
   constexpr int IT = L::KEYS * 8 / 256;  // = NB
   bf16x8 kreg[IT], vreg[IT];
+  ASTAMP(t0);
   // Q fragments of the wave's first 32-query block travel with the K/V staging loads (their latency used to
   // be exposed in front of every block: 14 % of the kernel)
   auto load_q = [&](bf16x8 (&qf)[4], int qb) {
@@ -79,6 +101,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const bf16_t* __restr
       vreg[it] = *reinterpret_cast<const bf16x8*>(src + 2 * D);
     }
   }
+#if ATTN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  ASTAMP(t1);
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int c = tid + it * 256;
@@ -87,11 +113,22 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const bf16_t* __restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16_t*>(Vt + (ch * 8 + e) * L::VSTRIDE + key * 2) = vreg[it][e];
   }
+  ASTAMP(t2);
   __syncthreads();
+  ASTAMP(t3);
+#if ATTN_STAMPS
+  unsigned long long a_q = 0, a_qk = 0, a_sm = 0, a_pv = 0, a_st = 0;
+#endif
 
   const int ksw = (r >> 1) & 7;
   for (int qb = wave; qb < NB; qb += 4) {
+    ASTAMP(s0);
     const int q = qb * 32 + r;
+
+#if ATTN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    ASTAMP(s1);
     // ---- Sᵀ[key][q] for all NB key blocks ---------------------------------------------------------
     // K fragments are double-buffered: the reads for d-slice s+1 are issued before the MFMAs of slice s,
     // so the matrix pipe never waits for an LDS read issued in the same group.
@@ -123,6 +160,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const bf16_t* __restr
     __builtin_amdgcn_sched_barrier(0);
     mma_k(kfb, 3);
     __builtin_amdgcn_sched_barrier(0);
+
+    ASTAMP(s2);
     // ---- softmax over the key axis: registers + one exchange with lane ^ 32 -----------------------
     // only the last key block can hold keys >= tokens (the launcher picks NB = ceil(tokens / 32))
 #pragma unroll
@@ -159,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const bf16_t* __restr
     l += __shfl_xor(l, 32, 64);
 
     if (qb + 4 < NB) load_q(qn, qb + 4);  // next block's Q fragments fly during the PV product
+    ASTAMP(s3);
     // ---- Oᵀ[d][q] = Σ_key Vt[d][key] · Pᵀ[key][q]; P fragments come straight from the S registers ------
     // Vt fragments (element j of lane half h is key 16s + 8(j>>2) + 4h + (j&3) of the block: two runs of 4
     // keys) are read one (block, slice) step ahead of the MFMAs that use them.
@@ -197,6 +237,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const bf16_t* __restr
       mma_v(vfb, step + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+
+    ASTAMP(s4);
     if (q < tokens) {
       const float inv = 1.0f / l;
       bf16_t* op = out + ((int64_t)frame * tokens + q) * ld_out + head * HD;
@@ -212,7 +254,21 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const bf16_t* __restr
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+#if ATTN_STAMPS
+    {
+      const unsigned long long s5 = astamp();
+      a_q += s1 - s0; a_qk += s2 - s1; a_sm += s3 - s2; a_pv += s4 - s3; a_st += s5 - s4;
+    }
+#endif
   }
+#if ATTN_STAMPS
+  if (tid == 0 && g_attn_dbg) {
+    float* d = g_attn_dbg + (int64_t)blockIdx.x * 12;
+    const unsigned long long te = astamp();
+    d[0] = (float)(t1 - t0); d[1] = (float)(t2 - t1); d[2] = (float)(t3 - t2);
+    d[3] = (float)a_q; d[4] = (float)a_qk; d[5] = (float)a_sm; d[6] = (float)a_pv; d[7] = (float)a_st; d[8] = (float)(te - t0);
+  }
+#endif
 }
 
 // ---- persistent variant (tokens <= 208) -----------------------------------------------------------------
@@ -422,6 +478,10 @@ __global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __
   if (wave > NB) return;
 
   // ---- the compute waves --------------------------------------------------------------------------------
+#if ATTN_STAMPS
+  unsigned long long a_w = 0, a_i = 0, a_qk = 0, a_sm = 0, a_pv = 0, a_st = 0;
+  const unsigned long long t_begin = astamp();
+#endif
   int frame, head, nframe = 0, nhead = 0;
   bool have = item_of(0, frame, head);
   for (int n = 0; have; ++n) {
@@ -429,10 +489,13 @@ __global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __
     const unsigned char* Ks = smem + cur * 2 * img;
     const unsigned char* Vs = Ks + img;
     unsigned char* Qs = qs0 + cur * NB * QIMG;
+    PSTAMP(p0);
     // The output stores of the previous item stay in flight: nothing here waits for them (a raw s_barrier;
     // __syncthreads() would add the workgroup release fence, i.e. a wait for those stores).
     barrier();
+    PSTAMP(p1);
     const bool have_next = item_of(n + 1, nframe, nhead);
+    PSTAMP(p2);
     {
     bf16x8 qf[4];
 #pragma unroll
@@ -466,6 +529,7 @@ __global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __
     mma_k(kfb, 3);
     __builtin_amdgcn_sched_barrier(0);
     barrier();  // every wave has read its K fragments (the loader may overwrite the K image); V is in
+    PSTAMP(p3);
 
     // ---- softmax over the key axis ------------------------------------------------------------------
 #pragma unroll
@@ -500,6 +564,7 @@ __global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __
     float l = ((lv[0] + lv[1]) + (lv[2] + lv[3])) + ((lv[4] + lv[5]) + (lv[6] + lv[7])) +
               (((lv[8] + lv[9]) + (lv[10] + lv[11])) + ((lv[12] + lv[13]) + (lv[14] + lv[15])));
     l += __shfl_xor(l, 32, 64);
+    PSTAMP(p4);
 
     // ---- Oᵀ[d][q] = Σ_key V[key][d] · Pᵀ[key][q]: V operand through the transposing read ------------
     // lane (r, h): d row r of tile dt, keys base + 4h + {0..3} and base + 8 + 4h + {0..3}.  In its 16-lane
@@ -542,6 +607,8 @@ __global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __
       mma_v(vfb, step + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+
+    PSTAMP(p5);
     // ---- output: [q][64] bf16 through my (consumed) Q image, then whole 128-byte lines --------------
     {
       const float inv = 1.0f / l;
@@ -564,11 +631,24 @@ __global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __
         __builtin_amdgcn_raw_buffer_store_b128(d, srdO, off, obase, 0);
       }
     }
+#if ATTN_STAMPS
+    {
+      const unsigned long long p6 = astamp();
+      a_w += p1 - p0; a_i += p2 - p1; a_qk += p3 - p2; a_sm += p4 - p3; a_pv += p5 - p4; a_st += p6 - p5;
+    }
+#endif
     }
     have = have_next;
     frame = nframe;
     head = nhead;
   }
+#if ATTN_STAMPS
+  if (lane == 0 && g_attn_dbg && wave < 2) {
+    float* d = g_attn_dbg + ((int64_t)blockIdx.x * 2 + wave) * 8;
+    d[0] = (float)a_w; d[1] = (float)a_i; d[2] = (float)a_qk; d[3] = (float)a_sm; d[4] = (float)a_pv; d[5] = (float)a_st;
+    d[6] = (float)(astamp() - t_begin);
+  }
+#endif
 }
 
 // 1 = not served (shape outside the persistent kernel's LDS budget or 32-bit offsets)
@@ -623,6 +703,9 @@ int launch(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, int n_fra
 
 }  // namespace
 
+#if ATTN_STAMPS
+extern "C" void dfd_attn_set_debug(float* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg), &p, sizeof(p)); }
+#endif
 
 int dfd_attention_mfma_try(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, int n_frames, int tokens, int heads,
                            float scale, hipStream_t st) {
