@@ -67,7 +67,8 @@ def parse():
     ap.add_argument("--ingest-size", type=int, nargs=2, default=None, metavar=("H", "W"),
                     help="with --ingest u8: source frame size (default = the model's resolution, i.e. no resize)")
     ap.add_argument("--spare-cus", type=int, default=-1, help="CUs the encoder GEMMs leave to the decoder stream in pipelined training (-1 = package default)")
-    ap.add_argument("--spare-layers", type=int, default=-1, help="encoder blocks at the start of a pass that leave the spare CUs free (-1 = package default, 0 = all)")
+    ap.add_argument("--spare-layers", type=int, default=-1, help="encoder blocks at the start of a pass whose GEMMs (--spare-gemms) leave the spare CUs free (-1 = package default, 0 = all)")
+    ap.add_argument("--spare-gemms", default=None, help="lab: comma list of the block's GEMMs (qkv,out,fc,proj) that leave the spare CUs free")
     ap.add_argument("--gemm-stream-out", default=None,
                     help="comma list of encoder GEMM outputs stored non-temporally (qkv,out,fc,proj; 'none'); default = package default")
     ap.add_argument("--adapter", default="none", choices=["none", "nln", "z0", "ln"],
@@ -104,6 +105,9 @@ def build_model(args, device):
         det.pipeline_spare_cus = args.spare_cus
     if args.spare_layers >= 0:
         det.pipeline_spare_layers = args.spare_layers
+    if args.spare_gemms is not None:
+        on = set(args.spare_gemms.split(",")) - {"none", ""}
+        det.encoder.spare_gemms = {k: k in on for k in det.encoder.spare_gemms}
     if args.gemm_stream_out is not None:
         on = set(args.gemm_stream_out.split(",")) - {"none", ""}
         det.encoder.stream_out = {k: k in on for k in det.encoder.stream_out}

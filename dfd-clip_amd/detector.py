@@ -242,8 +242,8 @@ class Detector(RuntimeStateMixin, nn.Module):
         self.kv_in_place = True  # without an adapter the decoder reads K/V out of the q|k|v activations (see `_encode`)
         self.inputs_ready = False
         self.pipeline_spare_cus = None  # None = one compute unit per shader engine (CUs / 8), see `_encode`
-        self.pipeline_spare_layers = 4  # encoder blocks at the start of a pass that leave those CUs free (0 = all): the
-                                        # previous step's decoder chain is done within about four blocks' time
+        self.pipeline_spare_layers = 0  # encoder blocks at the start of a pass that leave those CUs free (0 = all); which
+                                        # of a block's GEMMs do is `encoder.spare_gemms` (c_proj only: see there)
         self._enc_stream = None
         self._pipe_events = [[], []]
         self._pipe_step = 0
@@ -377,9 +377,10 @@ class Detector(RuntimeStateMixin, nn.Module):
             pos_ready = torch.cuda.Event()
             pos_ready.record(cur)
             pos = snap
-        # While a training step's backward / optimizer is what runs beside this pass, the persistent GEMMs leave one
-        # compute unit per shader engine free (MI355X: 32 of 256): the ~450 small dependent kernels of the decoder then
-        # never wait for a whole GEMM to end.  Measured (B16xT30 train step): 0-30 spare CUs 22.4-22.8 ms, 32-34 spare
+        # While a training step's backward / optimizer is what runs beside this pass, the persistent c_proj GEMM of every
+        # block leaves one compute unit per shader engine free (MI355X: 32 of 256): the ~450 small dependent kernels of
+        # the decoder then get a 0.4 ms window per block without waiting for a whole GEMM to end (round 2: every GEMM of
+        # the first four blocks did; c_proj alone, in every block, is 1.3 % faster and leaves c_fc its CUs).  Measured (B16xT30 train step): 0-30 spare CUs 22.4-22.8 ms, 32-34 spare
         # 20.9-21.0 ms, 40+ 22.0 ms (the encoder loses more than the overlap returns) — the workgroup dispatcher deals
         # workgroups to shader engines in turn, so a small kernel stalls as soon as ONE engine has no free CU.
         spare = self.pipeline_spare_cus

@@ -145,6 +145,9 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         # decoder's backward / optimizer of the previous step with this encoder pass
         self.spare_cus = 0
         self.spare_layers = 0  # ... and only in the first `spare_layers` blocks of a pass (0 = all of them)
+        # ... and only by these GEMMs of a block.  c_proj (N = D: 4.3 rounds of 256-row tiles on every CU, 5 either way on
+        # 224) gives its spare CUs away for free; q|k|v and c_fc pay a whole extra round of tiles for them
+        self.spare_gemms = {"qkv": False, "out": False, "fc": False, "proj": True}
 
     # ---- derived device-side operands ---------------------------------------------------
     @property
@@ -350,11 +353,13 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         f8 = self._fp8[bp["idx"]] if self.precision == "fp8" and calib is None else None
         so = self.stream_out
         sp = self.spare_cus if (self.spare_layers <= 0 or bp["idx"] < self.spare_layers) else 0
+        sg = self.spare_gemms
+        sp_qkv, sp_out, sp_fc, sp_proj = (sp if sg[k] else 0 for k in ("qkv", "out", "fc", "proj"))
         D = self.width
         # q | k | v projection (+ K/V export); the last tapped layer computes only the K and V thirds
         first = 1 if kv_only else 0
         rows = slice(D, None) if first else slice(None)
-        kw = dict(m=M, tokens=self.tokens, qkv_first=first, stream_out=so["qkv"], spare_cus=sp)
+        kw = dict(m=M, tokens=self.tokens, qkv_first=first, stream_out=so["qkv"], spare_cus=sp_qkv)
         if export is not None:
             kw.update(pos=export[2], k_export=export[0], v_export=export[1], frames_per_clip=export[3])
         if f8 is not None:
@@ -368,23 +373,23 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         if kv_only:
             return
         capi.attention_fwd(qkv, ws["mix"], n, self.tokens, self.heads)
-        self._residual(ws, ws["mix"], bp["w_out"], bp["b_out"], M, spare_cus=sp)
+        self._residual(ws, ws["mix"], bp["w_out"], bp["b_out"], M, spare_cus=sp_out)
         if f8 is not None:
             self._ln(ws, bp["ln2"], M, store=False, q=f8["h2_inv"])
             capi.gemm_fp8(ws["h8"], bp["w_fc8"], ws["u8"], f8["cs_fc"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M,
-                          out_inv_scale=f8["u_inv"], stream_out=so["fc"], spare_cus=sp)
+                          out_inv_scale=f8["u_inv"], stream_out=so["fc"], spare_cus=sp_fc)
             pend = ws.get("pending", 0)  # c_proj: the second deferred residual of the block (see `_residual`)
             capi.gemm_fp8(ws["u8"], bp["w_proj8"], ws["delta2" if pend else "delta"], f8["cs_proj"], bp["b_proj"], capi.EPI_BIAS, m=M,
-                          stream_out=so["proj"], spare_cus=sp)
+                          stream_out=so["proj"], spare_cus=sp_proj)
             ws["pending"] = pend + 1
         else:
             self._ln(ws, bp["ln2"], M, store=False)
             if calib is not None:
                 calib.append(ws["h"][:M].abs().max())
-            capi.gemm(ws["h"], bp["w_fc"], ws["u"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M, stream_out=so["fc"], spare_cus=sp)
+            capi.gemm(ws["h"], bp["w_fc"], ws["u"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M, stream_out=so["fc"], spare_cus=sp_fc)
             if calib is not None:
                 calib.append(ws["u"][:M].abs().max())
-            self._residual(ws, ws["u"], bp["w_proj"], bp["b_proj"], M, spare_cus=sp)
+            self._residual(ws, ws["u"], bp["w_proj"], bp["b_proj"], M, spare_cus=sp_proj)
 
     @torch.no_grad()
     def forward(self, x, with_out=False, with_q=False):
