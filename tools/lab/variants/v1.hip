@@ -14,7 +14,7 @@
 //     first K steps instead of in front of them;
 //   * epilogue staging lives in the 32 KB of LDS beside the 128 KB ring (4 KB per wave, 32 rows per pass).
 // Epilogues with a bf16 C: BIAS, BIAS_QUICKGELU, QKV_EXPORT (reference clip/model.py:186, :197, :208-212).
-#include "gemm256p_common.hpp"
+#include "../../../dfd-clip_amd/csrc/gemm256p_common.hpp"
 
 namespace {
 
