@@ -314,11 +314,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
       }
       // P0: k-half 0, rows 0-3 | prefetch rows 4-7 | request W of step kt+1 (a tile's step 1 is requested before its loop)
       phase(wA, lo, 0, [&] {
-        read_a(hi, slot, 0, 1);
         if (kt >= 1) {
           if (!last) issue_w(kt + 1, slot ^ 1);
           else if (has_next) issue_w(0, slot ^ 1);
         }
+        read_a(hi, slot, 0, 1);
       });
       // P1: k-half 0, rows 4-7 | prefetch k-half 1: W (second set) and rows 0-3
       phase(wA, hi, 1, [&] {
@@ -334,12 +334,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
       __builtin_amdgcn_sched_barrier(0);
       // P3: k-half 1, rows 4-7 (registers only) | first fragments of step kt+1 | request A of step kt+2
       phase(wB, hi, 1, [&] {
+        if (kt + 2 < nk) issue_a(kt + 2, slot);
+        else if (has_next) issue_a(kt + 2 - nk, slot);
         if constexpr (!last) {
           read_w(wA, slot ^ 1, 0);
           read_a(lo, slot ^ 1, 0, 0);
         }
-        if (kt + 2 < nk) issue_a(kt + 2, slot);
-        else if (has_next) issue_a(kt + 2 - nk, slot);
       });
     };
     if constexpr (F8) {

@@ -122,22 +122,17 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
 
   f32x4 acc[RB][4];
   auto phase = [&](const bf16x8 (&w)[4], const bf16x8 (&f)[4], int half, auto&& mid) {
-    constexpr int NB_ = 4;
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 4; ++j) acc[4 * half][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], f[0], acc[4 * half][j], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[4 * half + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], f[i], acc[4 * half + i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    for (int j = 0; j < 4; ++j) acc[4 * half + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], f[1], acc[4 * half + 1][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     mid();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 2; i < (half == 0 ? NB_ : HB); ++i)
+    for (int i = 2; i < (half == 0 ? 4 : HB); ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[4 * half + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], f[i], acc[4 * half + i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -251,12 +246,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
     // the groups of a step's first phases below the barrier, next to their consumers, and every operand of the step is
     // live at once)
     [[maybe_unused]] auto phase8 = [&](const v8i (&f)[2], int q, auto&& mid) {
-      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[2 * q + i][j] = mfma8(W8[j], f[i], acc[2 * q + i][j]);
-      __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -264,12 +257,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
       __builtin_amdgcn_sched_barrier(0);
       mid();
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int j = 2; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[2 * q + i][j] = mfma8(W8[j], f[i], acc[2 * q + i][j]);
-      __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int j = 2; j < 4; ++j)
 #pragma unroll
@@ -299,10 +290,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[6 + i][j] = mfma8(W8[j], aO[i], acc[6 + i][j]);
-        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(acc[6 + i][j]));
         __builtin_amdgcn_sched_barrier(0);
