@@ -12,9 +12,9 @@ int main() {
   const int64_t M = 480 * 197;
   struct Shape { const char* name; int N, K, epi; } shapes[] = {{"c_fc", 3072, 768, DFD_EPI_BIAS_QUICKGELU}, {"qkv", 2304, 768, DFD_EPI_BIAS}, {"c_proj", 768, 3072, DFD_EPI_BIAS}};
   typedef int (*fn_t)(const GemmArgs&, int, int, hipStream_t);
-  struct Var { const char* name; fn_t fn; } vars[] = {{"product", dfd_gemm256p_try}, {"v1 dma first", dfd_gemm256p_try_v1}, {"v2 free sched", dfd_gemm256p_try_v2},
-                                                      {"v3 8+8 nosp", dfd_gemm256p_try_v3}, {"product", dfd_gemm256p_try}, {"v1 dma first", dfd_gemm256p_try_v1},
-                                                      {"v2 free sched", dfd_gemm256p_try_v2}, {"v3 8+8 nosp", dfd_gemm256p_try_v3}};
+  struct Var { const char* name; fn_t fn; } vars[] = {{"product", dfd_gemm256p_try}, {"v1 W in P0+P1", dfd_gemm256p_try_v1}, {"v2 W with A P3", dfd_gemm256p_try_v2},
+                                                      {"v3 = product", dfd_gemm256p_try_v3}, {"product", dfd_gemm256p_try}, {"v1 W in P0+P1", dfd_gemm256p_try_v1},
+                                                      {"v2 W with A P3", dfd_gemm256p_try_v2}, {"v3 = product", dfd_gemm256p_try_v3}};
   for (auto& sh : shapes) {
     void *A, *W, *C; float* bias;
     hipMalloc(&A, M * sh.K * 2); hipMalloc(&W, (size_t)sh.N * sh.K * 2); hipMalloc(&C, M * sh.N * 2); hipMalloc(&bias, sh.N * 4);
