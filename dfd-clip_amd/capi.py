@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT, EPI_RESIDUAL_POS = range(6)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
 FP8 = 2           # ABI code of OCP e4m3; stored in uint8 / torch.float8_e4m3fn tensors
@@ -63,6 +63,8 @@ SIGNATURES = {
     "dfd_dropout": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, POINTER(DropoutDesc), c_void_p]),
     "dfd_device_check": (c_int, []),
     "dfd_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_float, c_float, c_void_p]),
+    "dfd_layernorm2": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_float,
+                               c_float, c_void_p]),
     "dfd_add_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_int, c_int64, c_int, c_float, c_float, c_void_p]),
     "dfd_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -168,6 +170,16 @@ def layernorm(x, gamma, beta, out, eps=1e-5, out_inv_scale=0.0):
     assert x.stride(1) == 1 and out.stride(1) == 1
     _check(load_library().dfd_layernorm(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(out), out.stride(0),
                                         _out_dtype(out), x.shape[0], x.shape[1], eps, float(out_inv_scale), _stream()), "dfd_layernorm")
+    return out
+
+
+def layernorm2(x, gamma_a, beta_a, gamma_b, beta_b, out, eps=1e-5, out_inv_scale=0.0):
+    """x <- LayerNorm_a(x) in place (f32), out = LayerNorm_b(x): one pass over the rows."""
+    _dev(x, gamma_a, beta_a, gamma_b, beta_b, out)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1 and out.shape == x.shape
+    _check(load_library().dfd_layernorm2(_ptr(x), x.stride(0), _ptr(gamma_a), _ptr(beta_a), _ptr(gamma_b), _ptr(beta_b), _ptr(out),
+                                         out.stride(0), _out_dtype(out), x.shape[0], x.shape[1], eps, float(out_inv_scale), _stream()),
+           "dfd_layernorm2")
     return out
 
 

@@ -244,10 +244,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
     // the groups of a step's first phases below the barrier, next to their consumers, and every operand of the step is
     // live at once)
     [[maybe_unused]] auto phase8 = [&](const v8i (&f)[2], int q, auto&& mid) {
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[2 * q + i][j] = mfma8(W8[j], f[i], acc[2 * q + i][j]);
+      __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -255,10 +257,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
       __builtin_amdgcn_sched_barrier(0);
       mid();
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int j = 2; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[2 * q + i][j] = mfma8(W8[j], f[i], acc[2 * q + i][j]);
+      __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int j = 2; j < 4; ++j)
 #pragma unroll
@@ -288,8 +292,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[6 + i][j] = mfma8(W8[j], aO[i], acc[6 + i][j]);
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(acc[6 + i][j]));
         __builtin_amdgcn_sched_barrier(0);

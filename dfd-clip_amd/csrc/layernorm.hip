@@ -104,6 +104,107 @@ static int launch_ln(const float* x, int64_t ldx, const float* g, const float* b
   return DFD_OK;
 }
 
+// Two LayerNorms back to back over the same rows in one pass: x <- LN_a(x) (f32, in place), y = LN_b(x).  The
+// encoder's ln_pre followed by the first block's ln_1 (clip/model.py:292, :221): the row stays in registers between
+// the two, so x is read once instead of twice.  Same arithmetic, in the same order, as two dfd_layernorm calls.
+template <typename OutT, int SLABS>
+__global__ __launch_bounds__(256) void layernorm2_rows_kernel(float* __restrict__ x, int64_t ldx, const float* __restrict__ ga,
+                                                              const float* __restrict__ ba, const float* __restrict__ gb,
+                                                              const float* __restrict__ bb, OutT* __restrict__ y, int64_t ldy,
+                                                              int64_t rows, int cols, float eps, float inv_scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* xr = x + row * ldx;
+  f32x4 v[SLABS];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < SLABS; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < cols) {
+        if (pass == 0) v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      } else {
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < SLABS; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < cols) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = v[i][j] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    const float* gamma = pass == 0 ? ga : gb;
+    const float* beta = pass == 0 ? ba : bb;
+#pragma unroll
+    for (int i = 0; i < SLABS; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < cols) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+        if (pass == 0) {
+          *reinterpret_cast<f32x4*>(xr + c) = o;
+          v[i] = o;
+        } else {
+          store_row4(y + row * ldy + c, o, inv_scale);
+        }
+      }
+    }
+  }
+}
+
+template <typename OutT>
+static int launch_ln2(float* x, int64_t ldx, const float* ga, const float* ba, const float* gb, const float* bb, void* y, int64_t ldy,
+                      int64_t rows, int cols, float eps, float inv_scale, hipStream_t st) {
+  const int slabs = (cols + 255) / 256;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  OutT* yo = static_cast<OutT*>(y);
+#define LN2_CASE(S)                                                                                    \
+  case S:                                                                                              \
+    hipLaunchKernelGGL((layernorm2_rows_kernel<OutT, S>), grid, block, 0, st, x, ldx, ga, ba, gb, bb, yo, ldy, rows, cols, eps, inv_scale); \
+    break;
+  switch (slabs) {
+    LN2_CASE(1) LN2_CASE(2) LN2_CASE(3) LN2_CASE(4) LN2_CASE(5) LN2_CASE(6) LN2_CASE(7) LN2_CASE(8)
+    default:
+      dfd_set_error("dfd_layernorm2: cols=%d > 2048 unsupported", cols);
+      return DFD_ERR_INVALID_ARG;
+  }
+#undef LN2_CASE
+  DFD_CHECK_LAUNCH("dfd_layernorm2");
+  return DFD_OK;
+}
+
+extern "C" int dfd_layernorm2(float* x, int64_t ldx, const float* gamma_a, const float* beta_a, const float* gamma_b,
+                              const float* beta_b, void* y, int64_t ldy, int y_dtype, int64_t rows, int cols, float eps,
+                              float y_inv_scale, void* stream) {
+  DFD_REQUIRE(x && gamma_a && beta_a && gamma_b && beta_b && y, "dfd_layernorm2: null pointer");
+  DFD_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "dfd_layernorm2: cols=%d must be a multiple of 4, <= 2048", cols);
+  DFD_REQUIRE(ldx >= cols && ldy >= cols && ldx % 4 == 0 && ldy % 4 == 0, "dfd_layernorm2: bad leading dimension (ldx=%lld ldy=%lld)", (long long)ldx, (long long)ldy);
+  DFD_REQUIRE(dfd_aligned16(x) && dfd_aligned16(gamma_a) && dfd_aligned16(beta_a) && dfd_aligned16(gamma_b) && dfd_aligned16(beta_b) &&
+                  ((uintptr_t)y & (y_dtype == DFD_FP8 ? 3 : 7)) == 0,
+              "dfd_layernorm2: pointers must be 16-byte aligned");
+  DFD_REQUIRE(y_dtype == DFD_F32 || y_dtype == DFD_BF16 || (y_dtype == DFD_FP8 && y_inv_scale > 0.f), "dfd_layernorm2: y_dtype=%d (fp8 needs y_inv_scale > 0)", y_dtype);
+  DFD_REQUIRE(static_cast<void*>(x) != y, "dfd_layernorm2: y must not alias x");
+  if (rows == 0) return DFD_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (y_dtype == DFD_F32) return launch_ln2<float>(x, ldx, gamma_a, beta_a, gamma_b, beta_b, y, ldy, rows, cols, eps, 1.f, st);
+  if (y_dtype == DFD_FP8) return launch_ln2<fp8_t>(x, ldx, gamma_a, beta_a, gamma_b, beta_b, y, ldy, rows, cols, eps, y_inv_scale, st);
+  return launch_ln2<bf16_t>(x, ldx, gamma_a, beta_a, gamma_b, beta_b, y, ldy, rows, cols, eps, 1.f, st);
+}
+
 extern "C" int dfd_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
                              int y_dtype, int64_t rows, int cols, float eps, float y_inv_scale, void* stream) {
   DFD_REQUIRE(x && gamma && beta && y, "dfd_layernorm: null pointer");

@@ -301,9 +301,9 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
             capi.patchify(frames, ws["patches"], self.input_resolution, self.patch_size)
         capi.gemm(ws["patches"], p["w_patch"], ws["x"], None, capi.EPI_PATCH_EMBED, m=n * P, pos=p["pos"], cls=p["cls"],
                   tokens=self.tokens)
-        M = n * self.tokens
         ws["pending"] = 0
-        capi.layernorm(ws["x"][:M], p["ln_pre"][0], p["ln_pre"][1], ws["x"][:M])
+        # ln_pre is not run here: the first block's ln_1 does it in the same pass over the rows (`_ln`, dfd_layernorm2)
+        ws["ln_pre"] = p["ln_pre"]
 
     def _ln(self, ws, gb, M, store=True, q=None):
         """h = LayerNorm(x).  On the bf16 path the residual branches that have not been added yet
@@ -313,7 +313,15 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         x = ws["x"]
         h, inv = (ws["h8"], q) if q is not None else (ws["h"], 0.0)  # q: e4m3 output with this inverse scale (fp8 path)
         pend = ws.get("pending", 0)
-        if pend == 0:
+        pre = ws.pop("ln_pre", None)
+        if pre is not None:  # first LayerNorm after the patch embedding: x <- ln_pre(x), h = ln_1(x), one pass
+            assert pend == 0
+            if self.width <= 2048:
+                capi.layernorm2(x[:M], pre[0], pre[1], gb[0], gb[1], h[:M], out_inv_scale=inv)
+            else:
+                capi.layernorm(x[:M], pre[0], pre[1], x[:M])
+                capi.layernorm(x[:M], gb[0], gb[1], h[:M], out_inv_scale=inv)
+        elif pend == 0:
             capi.layernorm(x[:M], gb[0], gb[1], h[:M], out_inv_scale=inv)
         elif not store:
             assert pend == 1

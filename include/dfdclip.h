@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DFD_ABI_VERSION 12
+#define DFD_ABI_VERSION 13
 
 enum { DFD_F32 = 0, DFD_BF16 = 1, DFD_FP8 = 2 /* OCP e4m3 ("e4m3fn"), one byte per element */ };
 
@@ -99,6 +99,12 @@ int dfd_device_check(void);                /* DFD_OK iff device 0.. current is g
  * cols % 4 == 0, cols <= 4096. */
 int dfd_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
                   int y_dtype, int64_t rows, int cols, float eps, float y_inv_scale, void* stream);
+
+/* Two LayerNorms back to back in one pass over the rows: x <- LayerNorm_a(x) (f32, in place), y = LayerNorm_b(x) — the
+ * encoder's ln_pre followed by the first block's ln_1 (clip/model.py:292, :221).  The same arithmetic, in the same order, as
+ * two dfd_layernorm calls (bit-identical); x is read once.  cols <= 2048; y must not alias x. */
+int dfd_layernorm2(float* x, int64_t ldx, const float* gamma_a, const float* beta_a, const float* gamma_b, const float* beta_b,
+                   void* y, int64_t ldy, int y_dtype, int64_t rows, int cols, float eps, float y_inv_scale, void* stream);
 /* y_dtype DFD_FP8 (both LayerNorm entry points): y = e4m3(LayerNorm(..) * y_inv_scale), saturated at +-448 — the A
  * operand of dfd_gemm_fp8; y_inv_scale is ignored for the other output types. */
 

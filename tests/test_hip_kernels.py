@@ -111,6 +111,21 @@ def test_patch_embed_is_conv1_plus_cls_plus_pos(capi, res, patch, width, dtype):
     assert_close(x.view(n, tokens, width), want, 2e-4 if dtype == torch.float32 else 2e-3, msg="patch embed")
 
 
+@pytest.mark.parametrize("rows,cols", [(5, 128), (1000, 768), (333, 1024), (7, 2048)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm2_is_two_layernorms(capi, rows, cols, dtype):
+    """dfd_layernorm2 (ln_pre + the first block's ln_1 in one pass over the rows) against two dfd_layernorm calls: the same
+    bits in x and in the output."""
+    x0 = rnd(rows, cols, seed=61).cuda()
+    ga, ba, gb, bb = (rnd(cols, seed=62 + i, scale=0.5).cuda() + (1.0 if i % 2 == 0 else 0.0) for i in range(4))
+    xa, ya = x0.clone(), torch.empty(rows, cols, device="cuda", dtype=dtype)
+    capi.layernorm(xa, ga, ba, xa)
+    capi.layernorm(xa, gb, bb, ya)
+    xb, yb = x0.clone(), torch.empty(rows, cols, device="cuda", dtype=dtype)
+    capi.layernorm2(xb, ga, ba, gb, bb, yb)
+    assert torch.equal(xa, xb) and torch.equal(ya, yb)
+
+
 @pytest.mark.parametrize("n,res,patch", [(3, 32, 16), (5, 224, 16), (2, 224, 32), (2, 64, 8)])
 def test_patchify_strip_kernel_matches_the_general_one(capi, n, res, patch):
     """bf16 patches of 4-aligned patch sizes come from the strip kernel (whole image rows in, one contiguous run out,
