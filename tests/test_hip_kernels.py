@@ -124,6 +124,9 @@ def test_layernorm2_is_two_layernorms(capi, rows, cols, dtype):
     xb, yb = x0.clone(), torch.empty(rows, cols, device="cuda", dtype=dtype)
     capi.layernorm2(xb, ga, ba, gb, bb, yb)
     assert torch.equal(xa, xb) and torch.equal(ya, yb)
+    if dtype == torch.float32:
+        with pytest.raises(capi.DfdError):
+            capi.layernorm2(xb, ga, ba, gb, bb, xb)  # y aliasing x is refused
 
 
 @pytest.mark.parametrize("n,res,patch", [(3, 32, 16), (5, 224, 16), (2, 224, 32), (2, 64, 8)])
@@ -480,6 +483,13 @@ def test_decoder_attention_reads_keys_and_values_in_place(capi, dtype, modes):
     got2 = run(kview.contiguous().view(B * S, D), vview.contiguous().view(B * S, D), pos)
     for a, b in zip(got2, want):
         assert torch.equal(bits(a), bits(b))
+    # rows that would not be 16-byte aligned are refused, not misread
+    if modes == 0:
+        odd = torch.zeros(B * T, tok, 3 * D + 2, device="cuda", dtype=dtype)
+        ws = torch.empty(capi.decoder_attn_workspace_bytes(B, H, 64, splits) // 4, **f32)
+        with pytest.raises(capi.DfdError):
+            capi.decoder_attn_fwd(q, odd[:, 1:, D:2 * D], odd[:, 1:, 2 * D:2 * D + D], m, torch.empty(B, D, **f32),
+                                  torch.empty(B, H, 2, **f32), ws, splits, B, T, P, H, pos=pos)
 
 
 @pytest.mark.parametrize("B,N,K", [(1, 8, 128), (2, 256, 128), (16, 1536, 768), (16, 768, 3072), (9, 100, 64)])
