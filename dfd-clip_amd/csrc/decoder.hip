@@ -23,7 +23,7 @@ constexpr int HD = 64;
 constexpr int PART = 2 + 2 * HD;  // floats per (clip, split, head): m, l, acc_s[64], acc_c[64]
 
 template <typename T, int MAXT, bool POS>
-__global__ __launch_bounds__(MAXT, (MAXT <= 512 ? 3 : 4)) void decoder_attn_partial_kernel(const float* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(MAXT, (MAXT <= 512 ? (POS ? 2 : 3) : 4)) void decoder_attn_partial_kernel(const float* __restrict__ q, const T* __restrict__ k,
                                                                     const T* __restrict__ v,
                                                                     const uint8_t* __restrict__ frame_mask,
                                                                     const float* __restrict__ ext_w,
