@@ -330,6 +330,11 @@ class Detector(RuntimeStateMixin, nn.Module):
                     shape = (len(self.layer_indices), b * t * P_, self.encoder.width)
                     new_set = lambda: (torch.empty(shape, device=x.device, dtype=self.encoder.act_dtype),
                                        torch.empty(shape, device=x.device, dtype=self.encoder.act_dtype))
+                if self._kv_static is not None and self._kv_static[0][4]:
+                    # pipelined and the batch shape changed (e.g. the last batch of an epoch): the previous steps' readers
+                    # of the old sets are tracked by events that are dropped below, and the allocator may hand the old
+                    # memory straight back — let the device finish first (rare, so a full drain is fine)
+                    torch.cuda.synchronize()
                 self._kv_static = None  # release the old sets before allocating the new ones
                 self._kv_static = (key, [new_set(), new_set()] if pipelined else [new_set()])
                 self._pipe_events = [[], []]

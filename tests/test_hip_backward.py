@@ -410,6 +410,42 @@ def test_pipelined_encoder_matches_eager_training(graphs, name):
         assert torch.equal(det_p(x, [y], m, single_task=0)[1][0], det_e.eval()(x, [y], m, single_task=0)[1][0])
 
 
+@pytest.mark.parametrize("graphs", [False, True])
+def test_pipelined_encoder_with_changing_batch_size(graphs):
+    """The pipelined path keeps persistent K/V buffer sets per batch shape; a shape change (the last batch of an epoch)
+    reallocates them while earlier steps may still be in flight.  Steps of 2, 1, 2, 2, 1 clips without host
+    synchronisation give the plain path's losses and parameters, bit for bit."""
+    import copy
+    case = build_case("small")
+    det_e = make_detector(case, "bf16")
+    det_p = copy.deepcopy(det_e)
+    det_p.pipeline_encoder, det_p.inputs_ready, det_p.static_graphs = True, True, graphs
+    x, m, y = case["x"].cuda(), case["m"].cuda(), case["y"].cuda()
+    batches = [(x, m, y), (x[:1], m[:1], y[:1]), (x.flip(0), m.flip(0), y.flip(0)), (x * 0.5, m, y), (x[1:], m[1:], y[1:])]
+    batches = [tuple(t.contiguous() for t in b) for b in batches]
+    torch.cuda.synchronize()
+
+    def run(det):
+        opt = det.configure_optimizers(0.01)
+        det.train()
+        out = []
+        for xs, ms, ys in batches:
+            opt.zero_grad(set_to_none=True)
+            losses, _, other = det(xs, [ys], ms, train=True, single_task=0)
+            (losses[0].mean() + sum(other.values())).backward()
+            opt.step()
+            out.append(losses[0].detach())
+        return out
+
+    lp = run(det_p)
+    torch.cuda.synchronize()
+    le = run(det_e)
+    for a, b in zip(lp, le):
+        assert torch.equal(a, b)
+    for (n, pe), (_, pp) in zip(det_e.named_parameters(), det_p.named_parameters()):
+        assert torch.equal(pe, pp), n
+
+
 @pytest.mark.parametrize("kv_in_place", [True, False])
 def test_pipelined_encoder_full_size_trainable_positional_embedding(kv_in_place):
     """kv_in_place: the default hand-over (the decoder reads K/V and the live positional embedding on the caller's
