@@ -174,7 +174,7 @@ class ClipTransform:
 
 
 class Detector(RuntimeStateMixin, nn.Module):
-    _RUNTIME_STATE = {"_kv_static": None, "_enc_stream": None, "_pipe_events": [[], []], "_pipe_step": 0, "_pos_snap": None,
+    _RUNTIME_STATE = {"_kv_static": None, "_kv_cache": {}, "_enc_stream": None, "_pipe_events": [[], []], "_pipe_step": 0, "_pos_snap": None,
                       "_drop_master": None}
 
     def invalidate_caches(self):
@@ -235,6 +235,7 @@ class Detector(RuntimeStateMixin, nn.Module):
         # opt-in: replay the decoder's training-step kernels as HIP graphs (fixed batch shape; see decoder.py)
         self.static_graphs = False
         self._kv_static = None
+        self._kv_cache = {}  # K/V buffer sets of the previous batch shape (see `_encode`)
         # opt-in: run the frozen encoder on its own stream so that step N+1's encoder pass overlaps step N's
         # decoder backward / all-reduce / optimizer (see `predict`); `inputs_ready` = the caller guarantees that
         # the clips handed to forward() are already complete in device memory
@@ -330,13 +331,21 @@ class Detector(RuntimeStateMixin, nn.Module):
                     shape = (len(self.layer_indices), b * t * P_, self.encoder.width)
                     new_set = lambda: (torch.empty(shape, device=x.device, dtype=self.encoder.act_dtype),
                                        torch.empty(shape, device=x.device, dtype=self.encoder.act_dtype))
-                if self._kv_static is not None and self._kv_static[0][4]:
-                    # pipelined and the batch shape changed (e.g. the last batch of an epoch): the previous steps' readers
-                    # of the old sets are tracked by events that are dropped below, and the allocator may hand the old
-                    # memory straight back — let the device finish first (rare, so a full drain is fine)
+                if self._kv_static is not None and (pipelined or self._kv_static[0][4]):
+                    # the batch shape or the mode changed (the last batch of an epoch, train <-> eval) around the pipelined
+                    # path: the readers of the old sets are tracked by events that are dropped below, and a set evicted
+                    # here may be handed back by the allocator and written by the encoder stream — let the device
+                    # finish first (a few times per epoch, so a full drain is fine)
                     torch.cuda.synchronize()
-                self._kv_static = None  # release the old sets before allocating the new ones
-                self._kv_static = (key, [new_set(), new_set()] if pipelined else [new_set()])
+                # the sets of the two most recent shapes are kept: going back to a shape finds its buffers at the same
+                # addresses, so the decoder's captured graphs for it stay valid epoch after epoch
+                if self._kv_static is not None:
+                    self._kv_cache[self._kv_static[0]] = self._kv_static[1]
+                sets = self._kv_cache.pop(key, None)
+                while len(self._kv_cache) > 1:
+                    self._kv_cache.pop(next(iter(self._kv_cache)))
+                self._kv_static = None
+                self._kv_static = (key, sets if sets is not None else ([new_set(), new_set()] if pipelined else [new_set()]))
                 self._pipe_events = [[], []]
                 self._pipe_step = 0
             slot = self._pipe_step % len(self._kv_static[1])
