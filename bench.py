@@ -350,9 +350,15 @@ def main():
         if fwd_only is not None:
             line["forward_only"] = {"value": round(fwd_only, 3), "unit": "clips/s", "workload": "BASELINE configs[1]: Detector.predict"}
         if world == 1 and not args.no_secondary and args.arch == "ViT-B/16" and args.precision == "bf16" and args.mode == "train":
-            line["secondary"] = secondary_configs(args, device)
+            try:  # informational: a failure here must not cost the headline line
+                line["secondary"] = secondary_configs(args, device)
+            except Exception as e:  # noqa: BLE001
+                line["secondary"] = [{"error": f"{type(e).__name__}: {e}"[:300]}]
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, sd, args)
+            try:
+                line["cpu_baseline"] = cpu_baseline(cfg, sd, args)
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"[:300]}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
