@@ -305,7 +305,7 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         # ln_pre is not run here: the first block's ln_1 does it in the same pass over the rows (`_ln`, dfd_layernorm2)
         ws["ln_pre"] = p["ln_pre"]
 
-    def _ln(self, ws, gb, M, store=True, q=None):
+    def _ln(self, ws, gb, M, store=True, q=None, discard_x=False):
         """h = LayerNorm(x).  On the bf16 path the residual branches that have not been added yet
         (`ws["pending"]` of them: out_proj wrote `ws["delta"]`, c_proj `ws["delta2"]`) are folded in first
         inside the same pass over the rows (dfd_add_layernorm).  ln_2 (`store=False`) normalises
@@ -323,6 +323,12 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
                 capi.layernorm(x[:M], gb[0], gb[1], h[:M], out_inv_scale=inv)
         elif pend == 0:
             capi.layernorm(x[:M], gb[0], gb[1], h[:M], out_inv_scale=inv)
+        elif discard_x:
+            # last block of an extraction pass (K and V thirds only): nothing reads the residual stream after this
+            # LayerNorm, so the sum is normalised without being stored (290 MB of writes less at B16xT30)
+            capi.add_layernorm(x[:M], ws["delta"][:M], gb[0], gb[1], h[:M], delta2=ws["delta2"][:M] if pend == 2 else None,
+                               store_x=False, out_inv_scale=inv)
+            ws["pending"] = 0
         elif not store:
             assert pend == 1
             capi.add_layernorm(x[:M], ws["delta"][:M], gb[0], gb[1], h[:M], store_x=False, out_inv_scale=inv)
@@ -371,10 +377,10 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         if export is not None:
             kw.update(pos=export[2], k_export=export[0], v_export=export[1], frames_per_clip=export[3])
         if f8 is not None:
-            self._ln(ws, bp["ln1"], M, q=f8["h1_inv"])
+            self._ln(ws, bp["ln1"], M, q=f8["h1_inv"], discard_x=kv_only)
             capi.gemm_fp8(ws["h8"], bp["w_qkv8"][rows], qkv[:, rows], f8["cs_qkv"][rows], bp["b_qkv"][rows], capi.EPI_QKV_EXPORT, **kw)
         else:
-            self._ln(ws, bp["ln1"], M)
+            self._ln(ws, bp["ln1"], M, discard_x=kv_only and calib is None)
             if calib is not None:
                 calib.append(ws["h"][:M].abs().max())
             capi.gemm(ws["h"], bp["w_qkv"][rows], qkv[:, rows], bp["b_qkv"][rows], capi.EPI_QKV_EXPORT, **kw)
