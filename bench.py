@@ -29,6 +29,26 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _launcher():
+    """dfd-clip_amd/launch.py loaded by path: the parent of a multi-rank run imports neither torch nor the HIP library."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_dfd_launch", os.path.join(ROOT, "dfd-clip_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+if __name__ == "__main__" and "--gpus" in " ".join(sys.argv[1:]):
+    # `python bench.py --gpus N` with N > 1 and no rendezvous in the environment: this process becomes the launcher
+    # (the reference's `accelerate launch`, scripts/cross-manipulation-train.sh:6) BEFORE anything can touch the GPU
+    _ap = argparse.ArgumentParser(add_help=False)
+    _ap.add_argument("--gpus", type=int, default=1)
+    _n = _ap.parse_known_args()[0].gpus
+    _l = _launcher()
+    if _n > 1 and not _l.under_launcher():
+        sys.exit(_l.spawn_ranks(_n, [os.path.abspath(__file__)] + sys.argv[1:]))
+
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md chip table
@@ -182,6 +202,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the environment describes {world} rank(s) (WORLD_SIZE): refusing to report a line whose n_gpus is wrong")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     if args.share_gpu:
         local = 0
@@ -195,6 +217,11 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(args.dist_backend)
+    ranks_seen = 1
+    if dist is not None:  # the world size the COLLECTIVE layer sees, not the one the environment claims
+        one = torch.ones(1, device=device if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
 
     from dfd_clip_amd import capi
     from dfd_clip_amd.weights import ARCHS
@@ -326,7 +353,7 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
         line = {
             "metric": f"1-sec clips/sec (30x224x224 frames) {args.arch}", "value": round(world * B * args.steps / dt, 3),
-            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "clips/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(host_enqueue_ms, 3), "host_cpu_ms_per_step": round(host_cpu_ms, 3),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic" if args.ingest == "f32" else "synthetic uint8 frames %dx%d" % tuple(x.shape[-2:]),

@@ -16,8 +16,28 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--pad", action="store_true", help="round M up to a multiple of 256 (what the encoder passes: padded workspaces)")
+    ap.add_argument("--shape", type=int, nargs=3, action="append", metavar=("M", "N", "K"),
+                    help="time this shape with the plain bias epilogue instead of the encoder's (repeatable), e.g. --shape 4096 4096 4096")
     args = ap.parse_args()
     capi.load_library()
+    if args.shape:
+        for M, N, K in args.shape:
+            a = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)  # uniform [-1, 1): the guide's GEMM figures are quoted on it
+            w = (torch.rand(N, K, device="cuda") * 2 - 1).to(torch.bfloat16)
+            bias = torch.zeros(N, device="cuda")
+            c = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+            for _ in range(5):
+                capi.gemm(a, w, c, bias, capi.EPI_BIAS)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.iters):
+                capi.gemm(a, w, c, bias, capi.EPI_BIAS)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            print(f"plain     M={M} N={N} K={K}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TFLOP/s")
+        return
     M = args.frames * 197
     if args.pad:
         M = (M + 255) // 256 * 256
