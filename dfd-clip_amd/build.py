@@ -17,6 +17,12 @@ LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# Kernels whose hand-counted `s_waitcnt vmcnt(N)` are exact only while the compiler adds no vector-memory operation of
+# its own: a register spill (scratch_store / scratch_load counts in vmcnt) would silently turn a wait into a race.  The
+# build asks the compiler for its resource report on these files and refuses a kernel with scratch.
+# (gemm256p.hip's fp8 forms reload two registers from scratch in their epilogue; its K loop waits for vmcnt(0) every
+# step, so that only over-waits there.  gemm256e.hip's loop never waits for zero.)
+NO_SCRATCH = {"gemm256e.hip": "gemm256e_kernel"}
 
 
 def _hipcc():
@@ -39,6 +45,21 @@ def _digest(paths):
     return h.hexdigest()
 
 
+def scratch_users(report, kernel_substr):
+    """From hipcc's -Rpass-analysis=kernel-resource-usage remarks: {kernel: bytes/lane} for kernels using scratch."""
+    import re
+    out, name = {}, None
+    for line in report.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            continue
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name and kernel_substr in name and int(m.group(1)) > 0:
+            out[name] = int(m.group(1))
+    return out
+
+
 def build(force=False, verbose=False, extra_flags=()):
     """Compile every .hip under csrc/ and link the shared library.  Returns its path.
     Incremental: an object is rebuilt when its source, a header or the flags changed."""
@@ -59,11 +80,16 @@ def build(force=False, verbose=False, extra_flags=()):
 
     def compile_one(job):
         sp, obj, stamp, dig = job
-        cmd = [hipcc, *FLAGS, *extra_flags, "-c", sp, "-o", obj]
+        guard = NO_SCRATCH.get(os.path.basename(sp))
+        cmd = [hipcc, *FLAGS, *extra_flags, *(["-Rpass-analysis=kernel-resource-usage"] if guard else []), "-c", sp, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {sp}:\n{r.stderr}")
-        if verbose and r.stderr.strip():
+        if guard:
+            bad = scratch_users(r.stderr, guard)
+            if bad:
+                raise RuntimeError(f"{sp}: kernels with hand-counted vmcnt waits must not use scratch, but: {bad}")
+        elif verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
         with open(stamp, "w") as f:
             f.write(dig)

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT, EPI_RESIDUAL_POS = range(6)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
 FP8 = 2           # ABI code of OCP e4m3; stored in uint8 / torch.float8_e4m3fn tensors
@@ -60,6 +60,7 @@ SIGNATURES = {
     "dfd_last_error": (c_char_p, []),
     "dfd_abi_version": (c_int, []),
     "dfd_gemm_last_path": (c_int, []),
+    "dfd_gemm_set_variant": (c_int, [c_int]),
     "dfd_dropout": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, POINTER(DropoutDesc), c_void_p]),
     "dfd_device_check": (c_int, []),
     "dfd_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_float, c_float, c_void_p]),
@@ -304,6 +305,11 @@ def gemm_fp8(a, w, c, col_scale, bias=None, epilogue=EPI_BIAS, m=None, out_inv_s
         e1.record()
         _profile["events"].append((e0, e1, 2.0 * M * N * K))
     return c
+
+
+def gemm_set_variant(variant):
+    """0 = every GEMM kernel eligible (default); 1 = skip the ping-pong kernel (tests / A-B runs).  Returns the previous value."""
+    return load_library().dfd_gemm_set_variant(int(variant))
 
 
 def gemm_last_path():

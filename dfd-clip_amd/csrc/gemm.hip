@@ -314,7 +314,13 @@ static int fill_extra(GemmArgs& a, int epilogue, const dfd_gemm_extra* extra, in
 }
 
 static thread_local int g_last_path = 0;
+static thread_local int g_gemm_variant = 0;
 extern "C" int dfd_gemm_last_path(void) { return g_last_path; }
+extern "C" int dfd_gemm_set_variant(int variant) {
+  const int old = g_gemm_variant;
+  g_gemm_variant = variant;
+  return old;
+}
 
 extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, int ab_dtype, void* C, int64_t ldc,
                         int c_dtype, const float* bias, int epilogue, const dfd_gemm_extra* extra, int64_t M, int N,
@@ -337,7 +343,10 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
   if (ab_dtype == DFD_BF16) {
     // a q|k|v projection without an export is a plain biased store
     const int epi_p = epilogue == DFD_EPI_QKV_EXPORT && a.k_export == nullptr ? DFD_EPI_BIAS : epilogue;
-    int rc = dfd_gemm256p_try(a, c_dtype, epi_p, st);
+    int rc = g_gemm_variant == 1 ? 1 : dfd_gemm256e_try(a, c_dtype, epi_p, st);  // ping-pong K loop (K a multiple of 128, >= 384)
+    if (rc == 0) g_last_path = 257;
+    if (rc <= 0) return rc;
+    rc = dfd_gemm256p_try(a, c_dtype, epi_p, st);
     if (rc == 0) g_last_path = 256;
     if (rc <= 0) return rc;
     rc = dfd_gemm256_try(a, c_dtype, epilogue, st);
@@ -366,7 +375,8 @@ extern "C" int dfd_gemm_fp8(const void* A, int64_t lda, const void* W, int64_t l
   { const int rc = fill_extra(a, epilogue, extra, c_dtype, ldc, M, N); if (rc != DFD_OK) return rc; }
   if (M == 0) return DFD_OK;
   const int epi_p = epilogue == DFD_EPI_QKV_EXPORT && a.k_export == nullptr ? DFD_EPI_BIAS : epilogue;
-  const int rc = dfd_gemm256p_f8_try(a, c_dtype, epi_p, static_cast<hipStream_t>(stream));
+  int rc = g_gemm_variant == 1 ? 1 : dfd_gemm256e_f8_try(a, c_dtype, epi_p, static_cast<hipStream_t>(stream));
+  if (rc == 1) rc = dfd_gemm256p_f8_try(a, c_dtype, epi_p, static_cast<hipStream_t>(stream));
   if (rc == 1) {
     dfd_set_error("dfd_gemm_fp8: shape not served (needs M >= 1024, N %% 256 == 0, K %% 128 == 0, K >= 256, 16-byte aligned rows; got M=%lld N=%d K=%d)",
                   (long long)M, N, K);

@@ -1,3 +1,5 @@
+// (Since round 3 the encoder's GEMMs run on gemm256e.hip, the same tile and ring with a ping-pong K loop; this kernel serves
+// the K depths that one does not: K / step odd or < 6.)
 // Persistent form of the tuned bf16 GEMM (gemm256.hip describes the 256x256 tile, the LDS ring, the XOR
 // swizzle and the four-phase K step; all of that is unchanged here).  What changes is what happens BETWEEN
 // tiles.  Ablations on MI355X (profiles/r02_gemm_ablation.txt) put the relaunching kernel's c_fc time at
@@ -509,7 +511,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
       }
     }
     if (!has_next) break;
-    s_prev = stores;
+    // A store whose lanes are all out of range is dropped by the buffer unit and retires at once, ahead of older loads
+    // (found with gemm256e.hip): the next tile's first wait may count this epilogue's stores only if every one of them
+    // was real, i.e. all of this wave's rows are inside M.
+    s_prev = (int64_t)cur.m0 + wr * WROWS + WROWS <= a.M ? stores : 0;
     par = (par + nk) & 1;
     idx = nidx;
     cur = nxt;

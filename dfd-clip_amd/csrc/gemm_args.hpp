@@ -28,3 +28,5 @@ struct GemmArgs {
 int dfd_gemm256_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st);   // gemm256.hip: one workgroup per tile
 int dfd_gemm256p_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st);  // gemm256p.hip: persistent, bf16 C
 int dfd_gemm256p_f8_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st);  // same kernel, e4m3 operands (dfd_gemm_fp8)
+int dfd_gemm256e_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st);     // gemm256e.hip: persistent, ping-pong K loop (tried first)
+int dfd_gemm256e_f8_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st);  // same kernel, e4m3 operands

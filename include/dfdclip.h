@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DFD_ABI_VERSION 13
+#define DFD_ABI_VERSION 14
 
 enum { DFD_F32 = 0, DFD_BF16 = 1, DFD_FP8 = 2 /* OCP e4m3 ("e4m3fn"), one byte per element */ };
 
@@ -157,9 +157,15 @@ int dfd_gemm_fp8(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
                  const float* col_scale, const float* bias, float out_inv_scale, int epilogue,
                  const dfd_gemm_extra* extra, int64_t M, int N, int K, void* stream);
 
-/* Which kernel served this thread's last successful dfd_gemm: 256 = the tuned 256x256 bf16 kernel (M >= 1024,
- * N % 256 == 0, K % 64 == 0, K >= 128), 128 = the general 128x128 kernel, 0 = none yet.  For tests and profilers. */
+/* Which kernel served this thread's last successful dfd_gemm: 257 = the persistent 256x256 kernel with the ping-pong
+ * K loop (M >= 1024, N % 256 == 0, K % 128 == 0, K >= 384), 256 = the other tuned 256x256 bf16 kernels (K % 64 == 0,
+ * K >= 128), 128 = the general 128x128 kernel, 0 = none yet.  For tests and profilers. */
 int dfd_gemm_last_path(void);
+
+/* Tests and A/B measurements: 0 (default) = every kernel eligible; 1 = skip the ping-pong kernel, so that the round-2
+ * persistent kernel serves the shapes both can (their results are bit-identical: tests/test_hip_kernels.py).  Per
+ * thread; returns the previous value. */
+int dfd_gemm_set_variant(int variant);
 
 /* C[Ma, Nb] (f32) = Aᵀ · B for tall row-major operands A [R, Ma], B [R, Nb] in `dtype` — the weight
  * gradient of a Linear applied to R rows (adapter training: R = B·T·patches).  Internally: zero-padded

@@ -97,6 +97,34 @@ def test_gemm_fp8_epilogues(capi, N, K):
         assert_close(ve.view(-1, tokens - 1, D), fv[:, 1:, 2] + pos_f, av[:, 1:, 2], RT, "v export")
 
 
+@pytest.mark.parametrize("M,N,K", [(1024 + 96, 768, 768), (20000, 3072, 1024), (70000, 1024, 4096)])
+def test_gemm_fp8_pingpong_equals_persistent(capi, M, N, K):
+    """Both persistent kernels serve these shapes (ping-pong K loop, round 3; one stream for all waves, round 2): same
+    operand layout, same accumulation order, so the same bits — bf16 and e4m3 outputs, ragged last row panel included."""
+    g = torch.Generator().manual_seed(M + K)
+    a8, _ = e4m3(torch.randn(M, K, generator=g) * 4.0)
+    w8, _ = e4m3(torch.randn(N, K, generator=g) * 8.0)
+    cs = (torch.rand(N, generator=g) * 0.02 + 0.001).cuda()
+    bias = (torch.randn(N, generator=g) * 0.1).cuda()
+
+    def run():
+        c = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        capi.gemm_fp8(a8, w8, c, cs, bias, capi.EPI_BIAS_QUICKGELU)
+        c8 = torch.zeros(M, N, device="cuda", dtype=torch.uint8)
+        capi.gemm_fp8(a8, w8, c8, cs, bias, capi.EPI_BIAS, out_inv_scale=0.5)
+        return c, c8
+
+    capi.gemm_set_variant(1)
+    try:
+        want = run()
+    finally:
+        capi.gemm_set_variant(0)
+    assert torch.isfinite(want[0].float()).all()
+    for _ in range(2):
+        got = run()
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
 def test_gemm_fp8_rejects_unserved_shapes(capi):
     a = torch.zeros(1024, 192, device="cuda", dtype=torch.uint8)
     w = torch.zeros(256, 192, device="cuda", dtype=torch.uint8)

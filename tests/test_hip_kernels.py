@@ -229,7 +229,8 @@ def test_gemm_tuned_kernel_every_epilogue(capi, M, N, K):
     RT = 2 ** -8
     c = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
     capi.gemm(a, w, c, bias, capi.EPI_BIAS)
-    assert capi.gemm_last_path() == 256, "this shape must run on the tuned kernel"
+    # K a multiple of 128 and >= 384: the ping-pong kernel (257); other depths: the round-2 persistent kernel (256)
+    assert capi.gemm_last_path() == (257 if K % 128 == 0 and K >= 384 and N % 256 == 0 else 256), "this shape must run on a tuned kernel"
     assert_close(c, ref, 1e-4, RT, "bias")
     c.fill_(float("nan"))
     capi.gemm(a, w, c, bias, capi.EPI_BIAS_QUICKGELU)
@@ -291,6 +292,8 @@ def test_persistent_gemm_variants_are_bit_identical(capi, M, N, K, epi):
         D = N // 3
         kw = dict(pos=torch.randn(T, D, device="cuda", generator=g), tokens=tokens, frames_per_clip=T)
 
+    expect_path = [257]  # the ping-pong kernel serves all four shapes; variant 1 hands them to the round-2 persistent kernel
+
     def run(**opts):
         c = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
         ex = {}
@@ -298,7 +301,7 @@ def test_persistent_gemm_variants_are_bit_identical(capi, M, N, K, epi):
             ex = dict(k_export=torch.full((M // tokens * (tokens - 1), N // 3), float("nan"), device="cuda", dtype=torch.bfloat16))
             ex["v_export"] = torch.full_like(ex["k_export"], float("nan"))
         capi.gemm(a, w, c, bias, e, **kw, **ex, **opts)
-        assert capi.gemm_last_path() == 256
+        assert capi.gemm_last_path() == expect_path[0]
         return [c] + list(ex.values())
 
     base = run(tile_blocks=8)
@@ -313,6 +316,45 @@ def test_persistent_gemm_variants_are_bit_identical(capi, M, N, K, epi):
         got = run(**opts)
         for x, y in zip(base, got):
             assert torch.equal(x, y), opts
+    # the round-2 persistent kernel (same tile, one instruction stream for all waves) gives the same bits
+    capi.gemm_set_variant(1)
+    expect_path[0] = 256
+    try:
+        for opts in (dict(tile_blocks=8), dict(tile_blocks=7, stream_out=True)):
+            got = run(**opts)
+            for x, y in zip(base, got):
+                assert torch.equal(x, y), ("persistent", opts)
+    finally:
+        capi.gemm_set_variant(0)
+
+
+@pytest.mark.parametrize("M", [1024, 1024 + 96, 256 * 40 + 8, 256 * 300 + 200])
+@pytest.mark.parametrize("N,K", [(256, 384), (768, 768), (1024, 4096)])
+def test_pingpong_gemm_ragged_panels_and_few_tiles(capi, M, N, K):
+    """The ping-pong kernel counts its vector-memory operations by hand.  Shapes that stress the counts: fewer tiles than
+    compute units (every workgroup's first tile is its last), a ragged last row panel (stores of rows beyond M are dropped
+    by the buffer unit and must not be counted by the next tile's waits), the shortest K it serves (head and tail of the K
+    loop back to back), many tiles per workgroup.  Against fp64, and bit for bit against the round-2 kernel, three times
+    (a race would not repeat)."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    ref = a.double() @ w.double().T + bias.double()
+    capi.gemm_set_variant(1)
+    try:
+        want = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        capi.gemm(a, w, want, bias, capi.EPI_BIAS_QUICKGELU)
+        assert capi.gemm_last_path() == 256
+    finally:
+        capi.gemm_set_variant(0)
+    assert_close(want, ref * torch.sigmoid(1.702 * ref), 1e-4, 2 ** -8, "round-2 kernel")
+    for rep in range(3):
+        for opts in (dict(), dict(tile_blocks=8, stream_out=True), dict(tile_blocks=7)):
+            c = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            capi.gemm(a, w, c, bias, capi.EPI_BIAS_QUICKGELU, **opts)
+            assert capi.gemm_last_path() == 257
+            assert torch.equal(c, want), (rep, opts)
 
 
 @pytest.mark.parametrize("res,patch,width", [(224, 16, 768), (224, 14, 1024)])

@@ -10,6 +10,7 @@ rm -f build/*.o
 hipcc $F -c ../../dfd-clip_amd/csrc/gemm256.hip -o build/k256.o &
 hipcc $F -c ../../dfd-clip_amd/csrc/gemm256p.hip -o build/k256p.o &
 hipcc $F -I../../include -c gemm256q_lab.hip -o build/k256q.o &
+hipcc $F -I../../include -save-temps=obj -c gemm256e_lab.hip -o build/k256e.o &
 wait
 hipcc $F -Wno-unused-result -Wno-unused-value -c gemm_lab.hip -o build/main.o
-hipcc --offload-arch=gfx950 build/main.o build/k256.o build/k256p.o build/k256q.o -o gemm_lab
+hipcc --offload-arch=gfx950 build/main.o build/k256.o build/k256p.o build/k256q.o build/k256e.o -o gemm_lab
