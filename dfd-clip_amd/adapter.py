@@ -24,11 +24,18 @@ out of place and keeps a1; the backward takes dK/dV from the decoder's attention
     dW0 = da1ᵀ · X                          [x, D]                  dfd_gemm_at_b
 The encoder output X needs no gradient (frozen encoder, reference models.py:440).
 """
+import collections
+import logging
+import weakref
+
 import torch
 from torch import nn
 
 from . import capi
 from .encoder import RuntimeStateMixin
+
+# captured forward / backward kernel sequences per adapter instance and input signature (as the decoder's: decoder.py)
+_GRAPHS = weakref.WeakKeyDictionary()
 
 # struct -> (index of the LayerNorm and of the output Linear inside the reference's nn.Sequential, kernel mode:
 # 0 = GELU(LN_row(a)), 1 = GELU(LN_joint(a)), 2 = LN_row(GELU(a)))   (reference models.py:795-875)
@@ -38,10 +45,12 @@ _SUPPORTED = tuple(_STRUCTS)
 
 
 class CompInvAdapter(RuntimeStateMixin, nn.Module):
-    _RUNTIME_STATE = {"_prep": None, "_after_backward": None}
+    _RUNTIME_STATE = {"_prep": None, "_after_backward": None, "_graphs_failed": None}
+    max_graphs = 4
 
     def invalidate_caches(self):
         self._prep = None
+        _GRAPHS.pop(self, None)
 
     def __init__(self, config, detector, num_frames=50):
         super().__init__()
@@ -79,6 +88,12 @@ class CompInvAdapter(RuntimeStateMixin, nn.Module):
                 setattr(self, f"l{i}_{j}", seq)
         self._prep = None
         self._after_backward = None  # one-shot callback for the next autograd node (Detector's encoder pipelining)
+        # training: replay the forward / backward kernel sequences as HIP graphs (`Detector.static_graphs`).  The ~170
+        # launches and ~100 small tensor ops of an adapter step then cost the host two graph launches; the outputs
+        # (k, v) = adapter(raw) + pos live in the graph's static buffers — what a call returned is overwritten by the
+        # next call with the same input buffers, and the decoder's own graphs find them at fixed addresses
+        self.use_graphs = False
+        self._graphs_failed = None
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -143,20 +158,24 @@ class CompInvAdapter(RuntimeStateMixin, nn.Module):
         # GELU-first structs keep the projection output in f32 (LayerNorm after the non-linearity amplifies
         # the rounding of its input ~4x more than the other order)
         a1_all = torch.empty(L, 2, rows, x, device=k_raw.device, dtype=torch.float32 if self.mode == 2 else act)
-        a2 = torch.empty(rows, x, device=k_raw.device, dtype=act)
+        # the second Linear's input (after the inner dropout) is kept as well: 48 MB per (layer, tensor) at B16xT30 buys the
+        # backward one normalisation pass less each
+        a2_all = torch.empty(L, 2, rows, x, device=k_raw.device, dtype=act)
         for i in range(L):
             for jj, (j, src, dst) in enumerate((("k", k_raw, k_out), ("v", v_raw, v_out))):
                 w0, lw, lb, w4 = sw[(i, j)]
                 inner, outer = self._drops(drop_rng, i, jj)
+                a2 = a2_all[i, jj]
                 capi.gemm(src[i], w0, a1_all[i, jj], None, capi.EPI_BIAS)
                 capi.adapter_norm_gelu(a1_all[i, jj], a2, lw, lb, frames, P, x, joint)
                 if inner is not None:
                     capi.dropout(a2, a2, inner)
                 capi.gemm(a2, w4, dst[i], None, capi.EPI_RESIDUAL_POS, pos=temporal_pos, tokens=P + 1, frames_per_clip=num_frames,
                           residual=src[i], drop=outer)
-        return k_out, v_out, a1_all
+        return k_out, v_out, (a1_all, a2_all)
 
-    def _backward_train(self, w, k_raw, v_raw, a1_all, dk, dv, drop_rng=None):
+    def _backward_train(self, w, k_raw, v_raw, saved, dk, dv, drop_rng=None):
+        a1_all, a2_all = saved
         act = k_raw.dtype
         sw = self._stage_weights(w, act)
         L, rows, D = k_raw.shape
@@ -165,7 +184,6 @@ class CompInvAdapter(RuntimeStateMixin, nn.Module):
         joint = self.mode
         dev = k_raw.device
         f32 = dict(device=dev, dtype=torch.float32)
-        a2 = torch.empty(rows, x, device=dev, dtype=act)
         da2 = torch.empty(rows, x, device=dev, dtype=act)
         da1 = torch.empty(rows, x, device=dev, dtype=act)
         nb = max(capi.gemm_at_b_workspace_bytes(rows, D, x, act), capi.gemm_at_b_workspace_bytes(rows, x, D, act))
@@ -184,10 +202,7 @@ class CompInvAdapter(RuntimeStateMixin, nn.Module):
                     d_o = capi.dropout(dout[i], d_masked, outer)
                 else:
                     d_o = dout[i].to(act) if dout.dtype != act else dout[i]
-                a1 = a1_all[i, jj]
-                capi.adapter_norm_gelu(a1, a2, lw, lb, frames, P, x, joint)
-                if inner is not None:
-                    capi.dropout(a2, a2, inner)
+                a1, a2 = a1_all[i, jj], a2_all[i, jj]
                 dw4 = torch.empty(D, x, **f32)
                 capi.gemm_at_b(d_o, a2, dw4, ws_ab)
                 w4t = w[pre + f"{self.out_idx}.weight"].float().t().contiguous().to(act)  # [x, D]: dA2 = dOut @ W4 as A @ (W4^T)^T
@@ -229,13 +244,91 @@ class CompInvAdapter(RuntimeStateMixin, nn.Module):
         return k_all, v_all
 
 
+    # ---- HIP-graph replay ------------------------------------------------------------------------------------------
+    def _graph_forward(self, w, k_raw, v_raw, num_frames, temporal_pos, drop_rng, params):
+        if self._graphs_failed:
+            return None
+        key = (k_raw.data_ptr(), v_raw.data_ptr(), tuple(k_raw.shape), str(k_raw.dtype), num_frames,
+               None if temporal_pos is None else tuple(temporal_pos.shape),
+               tuple(p.data_ptr() for p in params), drop_rng is not None, self.drop_inner, self.drop_outer, self.patches)
+        graphs = _GRAPHS.setdefault(self, collections.OrderedDict())
+        ent = graphs.get(key)
+        if ent is not None:
+            graphs.move_to_end(key)
+        else:
+            while len(graphs) >= self.max_graphs:
+                torch.cuda.synchronize()
+                graphs.popitem(last=False)
+            # `temporal_pos` is a fresh f32 copy of the parameter on every call: the graph reads a static copy of it,
+            # refreshed before each replay (as the dropout state)
+            ent = dict(bwd={}, rng=None if drop_rng is None else drop_rng.clone(),
+                       pos=None if temporal_pos is None else temporal_pos.clone())
+            self._forward_train(w, k_raw, v_raw, num_frames, ent["pos"], ent["rng"])  # eager once: lazy initialisations
+            torch.cuda.synchronize()
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    k_out, v_out, a1_all = self._forward_train(w, k_raw, v_raw, num_frames, ent["pos"], ent["rng"])
+            except Exception as e:  # capture is an optimisation: a runtime that refuses it leaves the eager launches
+                self._graphs_failed = f"{type(e).__name__}: {e}"
+                logging.warning("adapter: HIP graph capture failed, staying on eager launches (%s)", self._graphs_failed)
+                torch.cuda.synchronize()
+                return None
+            ent.update(fwd=g, k_out=k_out, v_out=v_out, a1_all=a1_all)
+            graphs[key] = ent
+        if drop_rng is not None:
+            ent["rng"].copy_(drop_rng)
+        if temporal_pos is not None:
+            ent["pos"].copy_(temporal_pos)
+        ent["fwd"].replay()
+        return ent
+
+    def _graph_backward(self, ent, w, k_raw, v_raw, dk, dv):
+        sig = (dk.data_ptr(), dv.data_ptr(), str(dk.dtype))
+        b = ent["bwd"].get(sig)
+        if b is None:
+            if len(ent["bwd"]) >= 2:  # gradient buffers keep moving (the decoder is not replaying graphs): copy into a static pair
+                sig = "static"
+                b = ent["bwd"].get(sig)
+        if b is None:
+            static = sig == "static"
+            b = dict(dk=dk.clone() if static else dk, dv=dv.clone() if static else dv, static=static)
+            self._backward_train(w, k_raw, v_raw, ent["a1_all"], b["dk"], b["dv"], ent["rng"])  # eager once
+            torch.cuda.synchronize()
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    grads = self._backward_train(w, k_raw, v_raw, ent["a1_all"], b["dk"], b["dv"], ent["rng"])
+            except Exception as e:
+                self._graphs_failed = f"{type(e).__name__}: {e}"
+                logging.warning("adapter: HIP graph capture of the backward failed, staying on eager launches (%s)", self._graphs_failed)
+                torch.cuda.synchronize()
+                return self._backward_train(w, k_raw, v_raw, ent["a1_all"], dk, dv, ent["rng"])
+            b.update(graph=g, grads=grads)
+            ent["bwd"][sig] = b
+        if b["static"]:
+            b["dk"].copy_(dk)
+            b["dv"].copy_(dv)
+        b["graph"].replay()
+        names = list(b["grads"])
+        src = [b["grads"][k] for k in names]
+        dst = [torch.empty_like(t) for t in src]  # autograd may keep or accumulate into what it is handed
+        torch._foreach_copy_(dst, src)
+        return dict(zip(names, dst))
+
+
 class _AdapterFn(torch.autograd.Function):
     """autograd node around the adapter's HIP forward / backward.  Outputs (k, v) = adapter(raw) + pos."""
 
     @staticmethod
     def forward(ctx, adapter, k_raw, v_raw, num_frames, temporal_pos, names, drop_rng, *params):
         w = {n: p.detach() for n, p in zip(names, params)}
-        k_out, v_out, a1_all = adapter._forward_train(w, k_raw, v_raw, num_frames, temporal_pos, drop_rng)
+        ent = adapter._graph_forward(w, k_raw, v_raw, num_frames, temporal_pos, drop_rng, params) if adapter.use_graphs else None
+        if ent is not None:
+            k_out, v_out, a1_all = ent["k_out"], ent["v_out"], ent["a1_all"]
+        else:
+            k_out, v_out, a1_all = adapter._forward_train(w, k_raw, v_raw, num_frames, temporal_pos, drop_rng)
+        ctx.graph_entry = ent
         ctx.adapter, ctx.w, ctx.names, ctx.drop_rng = adapter, w, names, drop_rng
         ctx.after_backward, adapter._after_backward = adapter._after_backward, None
         ctx.saved = (k_raw, v_raw, a1_all)
@@ -245,7 +338,10 @@ class _AdapterFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dk, dv):
         k_raw, v_raw, a1_all = ctx.saved
-        grads = ctx.adapter._backward_train(ctx.w, k_raw, v_raw, a1_all, dk.contiguous(), dv.contiguous(), ctx.drop_rng)
+        if ctx.graph_entry is not None:
+            grads = ctx.adapter._graph_backward(ctx.graph_entry, ctx.w, k_raw, v_raw, dk.contiguous(), dv.contiguous())
+        else:
+            grads = ctx.adapter._backward_train(ctx.w, k_raw, v_raw, a1_all, dk.contiguous(), dv.contiguous(), ctx.drop_rng)
         out = [grads.get(nm) if rq else None for nm, rq in zip(ctx.names, ctx.req)]
         if ctx.after_backward is not None:
             ctx.after_backward()

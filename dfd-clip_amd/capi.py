@@ -20,6 +20,7 @@ ABI_VERSION = 14
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
 FP8 = 2           # ABI code of OCP e4m3; stored in uint8 / torch.float8_e4m3fn tensors
 FP8_MAX = 448.0   # largest finite e4m3 value
+FP8_MIN_ROWS = 1024  # dfd_gemm_fp8 serves M >= 1024 (include/dfdclip.h)
 
 
 class DfdError(RuntimeError):

@@ -307,16 +307,27 @@ __global__ __launch_bounds__(512) void gemm256e_kernel(const GemmArgs a, int til
     using C2 = std::integral_constant<int, 2>;
     using C3 = std::integral_constant<int, 3>;
     using C4 = std::integral_constant<int, 4>;
-    ktile(0, C0{}, C0{}, C4{});
-    ktile(1, C1{}, C1{}, C4{});
-    for (int kt = 2; kt < nk - 4; kt += 2) {
-      ktile(kt, C0{}, C2{}, C4{});
-      ktile(kt + 1, C1{}, C2{}, C4{});
+    bool short_k = false;
+    if constexpr (EPI == DFD_EPI_RESIDUAL_POS) short_k = nk == 4;  // the adapter's x -> D Linear (x = 256): head and tail overlap
+    if (short_k) {
+      if constexpr (EPI == DFD_EPI_RESIDUAL_POS) {
+        ktile(0, C0{}, C0{}, C3{});
+        ktile(1, C1{}, C1{}, C2{});
+        ktile(2, C0{}, C2{}, C1{});
+        ktile(3, C1{}, C2{}, C0{});
+      }
+    } else {
+      ktile(0, C0{}, C0{}, C4{});
+      ktile(1, C1{}, C1{}, C4{});
+      for (int kt = 2; kt < nk - 4; kt += 2) {
+        ktile(kt, C0{}, C2{}, C4{});
+        ktile(kt + 1, C1{}, C2{}, C4{});
+      }
+      ktile(nk - 4, C0{}, C2{}, C3{});
+      ktile(nk - 3, C1{}, C2{}, C2{});
+      ktile(nk - 2, C0{}, C2{}, C1{});
+      ktile(nk - 1, C1{}, C2{}, C0{});
     }
-    ktile(nk - 4, C0{}, C2{}, C3{});
-    ktile(nk - 3, C1{}, C2{}, C2{});
-    ktile(nk - 2, C0{}, C2{}, C1{});
-    ktile(nk - 1, C1{}, C2{}, C0{});
 
     // ---- epilogue (gemm256p.hip's: bias, activation, LDS-staged whole-line stores, left in flight) -------------------
     // Every address below is rebuilt from an opaque copy of the lane id (left to itself the compiler hoists two dozen
@@ -411,7 +422,80 @@ __global__ __launch_bounds__(512) void gemm256e_kernel(const GemmArgs a, int til
         }
         return v;
       };
-      if constexpr (CF8) {
+      if constexpr (EPI == DFD_EPI_RESIDUAL_POS) {
+        // C(bf16) = residual + dropout(acc) + pos[(row / rows_per_frame) % T], rounded ONCE (the adapter's second Linear,
+        // reference models.py:795-875, :930-940; gemm256.hip has the one-workgroup-per-tile form of the same arithmetic).
+        // RB sub-passes of 16 rows parked as f32 (4 KB); the drain reads the residual row segment and the positional
+        // embedding (requested at the top of the sub-pass), adds and rounds; 2 stores of 8 rows x 128 B per sub-pass.
+        unsigned char* const parkf = ep + er * 256;  // unit (j*4 + eq) ^ er of a 256-byte row
+        const uint32_t cbase = (uint32_t)((mrow0 * a.ldc + nb + dc * 8) * 2);
+        // The residual and the embedding of sub-pass i + 1 are requested before sub-pass i is drained (one sub-pass of
+        // loads always in flight: with each load waited for where it is issued the epilogue is a chain of 2 RB memory
+        // round trips, 29 us per tile).  Inline-asm loads, counted by hand like the K loop's: queue at the wait of sub-pass
+        // i = [loads i][2 stores of i-1][6 loads of i+1].
+        const v4i srdRw = a.residual ? words(reinterpret_cast<const float*>(a.residual), (int)(uint32_t)(a.M * a.ldc * 2))
+                                     : words(reinterpret_cast<const float*>(a.C), (int)(uint32_t)(a.M * a.ldc * 2));
+        const v4i srdQw = words(a.pos ? a.pos : reinterpret_cast<const float*>(a.W), a.pos ? a.frames_per_clip * a.N * 4 : 0);
+        f32x4 pq[2][2][2];
+        v4i oq[2][2];
+        uint32_t offq[2][2], gq[2][2];
+        auto request = [&](int i, int b) {
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int rloc = i * 16 + rr * 8;
+            const uint32_t m = (uint32_t)min(mrow0 + rloc, a.M - 1);
+            const uint32_t frame = a.div_tokens.div(m);  // rows per frame = tokens - 1 (the export has no CLS row)
+            const uint32_t t = frame - a.div_frames.div(frame) * (uint32_t)a.frames_per_clip;
+            offq[b][rr] = rloc < rows_left ? cbase + (uint32_t)rloc * (uint32_t)(a.ldc * 2) : 0xffffffffu;
+            gq[b][rr] = m * (uint32_t)(a.N >> 3) + (uint32_t)((nb + dc * 8) >> 3);  // dropout group (the launcher checks M * N / 8 < 2^32)
+            const uint32_t poff = a.pos ? (t * (uint32_t)a.N + (uint32_t)(nb + dc * 8)) * 4 : 0xffffffffu;  // no embedding: out of range reads 0
+            asm volatile(
+                "s_nop 4\n\t"
+                "buffer_load_dwordx4 %0, %3, %5, 0 offen\n\t"
+                "buffer_load_dwordx4 %1, %3, %5, 0 offen offset:16\n\t"
+                "buffer_load_dwordx4 %2, %4, %6, 0 offen"
+                : "=&v"(pq[b][rr][0]), "=&v"(pq[b][rr][1]), "=&v"(oq[b][rr])
+                : "v"(poff), "v"(offq[b][rr]), "s"(srdQw), "s"(srdRw)
+                : "memory");
+          }
+        };
+        request(0, 0);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          __builtin_amdgcn_sched_barrier(0);
+          const int b = i & 1;
+          if (i + 1 < RB) request(i + 1, b ^ 1);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(parkf + (((j * 4 + eq) ^ er) << 4)) = acc[i][j];
+          if (i == 0) wait_vm<6>();
+          else if (i + 1 < RB) wait_vm<8>();
+          else wait_vm<2>();
+          asm volatile("" : "+v"(pq[b][0][0]), "+v"(pq[b][0][1]), "+v"(oq[b][0]), "+v"(pq[b][1][0]), "+v"(pq[b][1][1]), "+v"(oq[b][1]));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int row = rr * 8 + drow;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(ep + row * 256 + (((2 * dc) ^ row) << 4));
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(ep + row * 256 + (((2 * dc + 1) ^ row) << 4));
+            float dv[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              dv[e] = x0[e];
+              dv[4 + e] = x1[e];
+            }
+            // the adapter's last nn.Dropout, before the residual add: element index row * N + column (a multiple of 8)
+            dfd_drop_eight(a.drop, (uint64_t)gq[b][rr] << 3, dv);
+            const bf16x8 ob = __builtin_bit_cast(bf16x8, oq[b][rr]);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o[e] = (bf16_t)((float)ob[e] + dv[e] + pq[b][rr][0][e]);
+              o[4 + e] = (bf16_t)((float)ob[4 + e] + dv[4 + e] + pq[b][rr][1][e]);
+            }
+            store_out(__builtin_bit_cast(v4i, o), srdC, offq[b][rr], a.stream_out);
+          }
+        }
+      } else if constexpr (CF8) {
         // C as e4m3 of value * out_inv_scale: 4 passes of 32 rows x 64 B parked (2 KB); 8 wave-stores of 16 rows x 64 B
         stores = RB;
         const int srow = le >> 2, sc = le & 3;  // drain: row srow of a 16-row group, 16-byte chunk sc
@@ -509,7 +593,9 @@ int launch256e(const GemmArgs& a, hipStream_t st) {
     const int64_t tiles = ((a.M + rows - 1) / rows) * tiles_n;
     return (double)((tiles + cus - 1) / cus);
   };
-  const bool use224 = !F8 && (a.tile_rows == 224 || (a.tile_rows == 0 && rounds(224) * 0.97 < rounds(256)));
+  // (RESIDUAL_POS: 224-row tiles only — with 128 accumulator registers its read-modify-write epilogue, which also draws
+  // the dropout mask, does not fit the register file without spilling, and a spill would break the counted waits)
+  const bool use224 = !F8 && (EPI == DFD_EPI_RESIDUAL_POS || a.tile_rows == 224 || (a.tile_rows == 0 && rounds(224) * 0.97 < rounds(256)));
   const int rows = use224 ? 224 : 256;
   const int tiles_m = (int)((a.M + rows - 1) / rows);
   const int64_t ntiles = (int64_t)tiles_m * tiles_n;
@@ -518,7 +604,7 @@ int launch256e(const GemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((gemm256e_kernel<EPI, 8, true, CF8>), dim3(grid), dim3(512), 0, st, a, tiles_m, tiles_n);
   } else {
     if (use224) hipLaunchKernelGGL((gemm256e_kernel<EPI, 7, false, false>), dim3(grid), dim3(512), 0, st, a, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((gemm256e_kernel<EPI, 8, false, false>), dim3(grid), dim3(512), 0, st, a, tiles_m, tiles_n);
+    else if constexpr (EPI != DFD_EPI_RESIDUAL_POS) hipLaunchKernelGGL((gemm256e_kernel<EPI, 8, false, false>), dim3(grid), dim3(512), 0, st, a, tiles_m, tiles_n);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -529,9 +615,9 @@ int launch256e(const GemmArgs& a, hipStream_t st) {
 }
 
 // shared eligibility: 0 = fine, 1 = not served
-int check256e(const GemmArgs& a, int esz, int csz, int kstep) {
+int check256e(const GemmArgs& a, int esz, int csz, int kstep, bool short_k_ok = false) {
   const int nk = a.K / kstep;  // the loop is unrolled in pairs of K tiles around a head of two and a tail of four
-  if (a.N % TN != 0 || a.K % kstep != 0 || nk < 6 || (nk & 1) || a.M < 1024) return 1;
+  if (a.N % TN != 0 || a.K % kstep != 0 || (nk < 6 && !(short_k_ok && nk == 4)) || (nk & 1) || a.M < 1024) return 1;
   if ((a.ldw * esz) % 128 != 0) return 1;  // the second piece of a W unit is addressed as (first ^ 64) + 8 rows
   if ((a.lda * esz) % 16 != 0 || (a.ldw * esz) % 16 != 0 || (a.ldc * csz) % 16 != 0) return 1;
   if ((reinterpret_cast<uintptr_t>(a.A) & 15) != 0 || (reinterpret_cast<uintptr_t>(a.W) & 15) != 0 || (reinterpret_cast<uintptr_t>(a.C) & 15) != 0) return 1;
@@ -553,7 +639,7 @@ int check_export_e(const GemmArgs& a) {
 
 // 0 = launched, <0 = error, 1 = shape / epilogue not served by this kernel
 int dfd_gemm256e_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st) {
-  if (c_dtype != DFD_BF16 || check256e(a, 2, 2, 64)) return 1;
+  if (c_dtype != DFD_BF16 || check256e(a, 2, 2, 64, epi == DFD_EPI_RESIDUAL_POS)) return 1;
   switch (epi) {
     case DFD_EPI_BIAS:
       return launch256e<DFD_EPI_BIAS, false, false>(a, st);
@@ -565,6 +651,15 @@ int dfd_gemm256e_try(const GemmArgs& a, int c_dtype, int epi, hipStream_t st) {
       b.div_tokens = FastDiv::make((uint32_t)a.tokens);
       b.div_frames = FastDiv::make((uint32_t)a.frames_per_clip);
       return launch256e<DFD_EPI_QKV_EXPORT, false, false>(b, st);
+    }
+    case DFD_EPI_RESIDUAL_POS: {
+      if (check256e(a, 2, 2, 64, true) || a.tokens < 2 || a.M * (int64_t)(a.N >> 3) >= ((int64_t)1 << 32)) return 1;
+      if (a.pos && ((reinterpret_cast<uintptr_t>(a.pos) & 15) != 0 || a.frames_per_clip < 1)) return 1;
+      if (a.residual && (reinterpret_cast<uintptr_t>(a.residual) & 15) != 0) return 1;
+      GemmArgs b = a;
+      b.div_tokens = FastDiv::make((uint32_t)(a.tokens - 1));  // rows per frame
+      b.div_frames = FastDiv::make((uint32_t)(a.frames_per_clip > 0 ? a.frames_per_clip : 1));
+      return launch256e<DFD_EPI_RESIDUAL_POS, false, false>(b, st);
     }
     default:
       return 1;

@@ -13,6 +13,7 @@ Kernel sequence per block, rows = clips (B), everything f32 except the K/V strea
   -> dfd_linear_rows(out_proj, +residual) -> LayerNorm -> dfd_linear_rows(c_fc, QuickGELU)
   -> dfd_linear_rows(c_proj, +residual); then dfd_head_fwd (ln_post, projection, 5·z/‖z‖).
 """
+import collections
 import weakref
 
 import logging
@@ -462,6 +463,19 @@ class Decoder(RuntimeStateMixin, nn.Module):
 
 
     # ---- HIP-graph replay of the training-step kernel sequences --------------------------------
+    max_graphs = 8
+
+    def drop_graphs_for(self, data_ptrs):
+        """Forget the captured graphs that read K/V buffers at these addresses (the buffers are being released)."""
+        graphs = _GRAPHS.get(self)
+        if not graphs:
+            return
+        stale = [k for k in graphs if k[0] in data_ptrs or k[1] in data_ptrs]
+        if stale:
+            torch.cuda.synchronize()
+            for k in stale:
+                del graphs[k]
+
     def _graph_key(self, k_all, v_all, mask, dims, params, dropping, kv_pos=None):
         return (k_all.data_ptr(), v_all.data_ptr(), str(k_all.dtype), tuple(k_all.shape), tuple(k_all.stride()), dims, tuple(mask.shape),
                 None if kv_pos is None else kv_pos.data_ptr(),
@@ -472,11 +486,17 @@ class Decoder(RuntimeStateMixin, nn.Module):
         if self._graphs_failed:
             return None
         key = self._graph_key(k_all, v_all, mask, dims, params, drop_rng is not None, kv_pos)
-        graphs = _GRAPHS.setdefault(self, {})
+        graphs = _GRAPHS.setdefault(self, collections.OrderedDict())
         ent = graphs.get(key)
+        if ent is not None:
+            graphs.move_to_end(key)
         if ent is None:
-            if len(graphs) >= 4:  # addresses keep changing: graphs cannot help, stay eager
-                return None
+            # least recently used out: a training run cycles through a handful of signatures (full and last batch of an
+            # epoch, two K/V sets each when the encoder is pipelined); an entry whose K/V buffers were released never comes
+            # back and must not pin the cache (round 2 capped it at four and then stayed eager for good)
+            while len(graphs) >= self.max_graphs:
+                torch.cuda.synchronize()  # a replay of the entry may still be executing
+                graphs.popitem(last=False)
             # the dropout state is read from device memory by the kernels: the graph owns a static copy that is
             # refreshed before every replay, so each step draws new masks and its backward regenerates them
             ent = dict(mask=mask.clone(), bwd={}, rng=None if drop_rng is None else drop_rng.clone())

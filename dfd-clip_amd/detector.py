@@ -235,7 +235,8 @@ class Detector(RuntimeStateMixin, nn.Module):
         # opt-in: replay the decoder's training-step kernels as HIP graphs (fixed batch shape; see decoder.py)
         self.static_graphs = False
         self._kv_static = None
-        self._kv_cache = {}  # K/V buffer sets of the previous batch shape (see `_encode`)
+        self._kv_cache = {}  # K/V buffer sets of earlier batch signatures (see `_encode`)
+        self.kv_cache_sets = 4  # signatures whose sets stay allocated: train / eval x full batch / last batch of an epoch
         # opt-in: run the frozen encoder on its own stream so that step N+1's encoder pass overlaps step N's
         # decoder backward / all-reduce / optimizer (see `predict`); `inputs_ready` = the caller guarantees that
         # the clips handed to forward() are already complete in device memory
@@ -321,7 +322,9 @@ class Detector(RuntimeStateMixin, nn.Module):
         # persistent buffers: the opt-in modes, and in-place inference (nothing outlives the call there); an in-place
         # TRAINING forward outside those modes gets a buffer of its own, because its autograd node reads it later
         if keep or pipelined or (in_place and not torch.is_grad_enabled()):
-            key = (b, t, tuple(x.shape[-2:]), x.dtype, pipelined, pos is None, in_place)
+            # training and inference keep separate sets: an evaluation pass between two epochs must not evict (and so
+            # re-address) the buffers the training graphs were captured on
+            key = (b, t, tuple(x.shape[-2:]), x.dtype, pipelined, pos is None, in_place, bool(torch.is_grad_enabled() and self.training))
             if self._kv_static is None or self._kv_static[0] != key:
                 P_ = (self.encoder.input_resolution // self.encoder.patch_size) ** 2
                 if in_place:
@@ -337,13 +340,23 @@ class Detector(RuntimeStateMixin, nn.Module):
                     # here may be handed back by the allocator and written by the encoder stream — let the device
                     # finish first (a few times per epoch, so a full drain is fine)
                     torch.cuda.synchronize()
-                # the sets of the two most recent shapes are kept: going back to a shape finds its buffers at the same
-                # addresses, so the decoder's captured graphs for it stay valid epoch after epoch
+                # the sets of the most recent signatures are kept (train / eval x full / last batch of an epoch): going back
+                # to one finds its buffers at the same addresses, so the decoder's captured graphs for it stay valid epoch
+                # after epoch; what is evicted takes its graphs with it
                 if self._kv_static is not None:
                     self._kv_cache[self._kv_static[0]] = self._kv_static[1]
                 sets = self._kv_cache.pop(key, None)
-                while len(self._kv_cache) > 1:
-                    self._kv_cache.pop(next(iter(self._kv_cache)))
+                while len(self._kv_cache) > self.kv_cache_sets - 1:
+                    gone = self._kv_cache.pop(next(iter(self._kv_cache)))
+                    ptrs = set()
+                    for s_ in gone:
+                        for t_ in (s_ if isinstance(s_, tuple) else (s_,)):
+                            ptrs.add(t_.data_ptr())
+                            if t_.dim() == 4:  # in-place sets: the decoder sees the K and V thirds as strided views
+                                D_ = t_.shape[-1] // 3
+                                ptrs.add(t_[:, :, 1:, D_:2 * D_].data_ptr())
+                                ptrs.add(t_[:, :, 1:, 2 * D_:].data_ptr())
+                    self.decoder.drop_graphs_for(ptrs)
                 self._kv_static = None
                 self._kv_static = (key, sets if sets is not None else ([new_set(), new_set()] if pipelined else [new_set()]))
                 self._pipe_events = [[], []]
@@ -423,6 +436,8 @@ class Detector(RuntimeStateMixin, nn.Module):
         # differentiable w.r.t. its own parameters
         pos = self.decoder.temporal_pos()
         self.decoder.use_graphs = False
+        if self.adapter is not None:
+            self.adapter.use_graphs = False
         pipe = None
         drop_rng = self._next_drop_rng(x.device)
         masked = train and "patch_mask" in self.train_mode
@@ -457,7 +472,9 @@ class Detector(RuntimeStateMixin, nn.Module):
         else:
             # raw K/V export, then adapter(kv) + pos (models.py:546-549, :326-329); differentiable w.r.t. the
             # adapter's parameters when they are trainable
-            kv, pipe = self._encode(x, t, None, keep=False, allow_in_place=False)
+            graphs = bool(self.static_graphs and train and torch.is_grad_enabled())
+            self.adapter.use_graphs = self.decoder.use_graphs = graphs
+            kv, pipe = self._encode(x, t, None, keep=graphs, allow_in_place=False)
             if pipe is not None:
                 self.adapter._after_backward = pipe[3].record  # its backward is the last reader of the raw export
             kv = self.adapter.run(kv[0], kv[1], t, pos, drop_rng)

@@ -136,7 +136,9 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         # bf16 path: residual branches are stored as bf16 deltas and added inside the next LayerNorm
         # (see `_residual`); the fp32 parity path keeps the read-modify-write epilogue
         self.deferred_residual = precision in ("bf16", "fp8")
-        self._fp8 = None  # fp8 path: per-layer activation scales and column-scale vectors (calibrate_fp8)
+        self._fp8 = None  # fp8 path: per-layer activation scales and column-scale vectors, DERIVED from the two below
+        self._fp8_amax = None  # ... the calibrated activation maxima [layers, 3] (host, f32): survive .to() / load_state_dict /
+        self._fp8_margin = 1.0  # broadcasts (which only invalidate what is derived from the weights); `fp8_calibration()`
         self._calib = None
         # which GEMM outputs are stored non-temporally (capi.gemm stream_out): they are written once and read back only
         # after other traffic has flushed the caches anyway, and keeping them out of L2 leaves the operand panels there
@@ -160,7 +162,7 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
 
     # ---- fp8 activation scales ------------------------------------------------------------------
     def _ensure_fp8(self, frames):
-        if self.precision == "fp8" and self._fp8 is None and getattr(self, "_calib", None) is None:
+        if self.precision == "fp8" and self._fp8_amax is None and getattr(self, "_calib", None) is None:
             import logging
             logging.warning("fp8 encoder: no calibration yet, taking the activation scales from this batch "
                             "(call encoder.calibrate_fp8(frames) with representative frames to fix them beforehand)")
@@ -187,14 +189,33 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
             self._calib = None
             self._ws.pop((n, self.precision, 1, 99), None)
         amax = torch.stack(rec).view(len(p["blocks"]), 3).float().cpu()  # one host sync, at calibration time only
-        scales = (amax * margin / capi.FP8_MAX).clamp_min(1e-12)
-        layers = []
-        for l, bp in enumerate(p["blocks"]):
-            s1, s2, su = (float(v) for v in scales[l])
-            layers.append(dict(h1_inv=1.0 / s1, h2_inv=1.0 / s2, u_inv=1.0 / su, cs_qkv=(bp["s_qkv"] * s1).contiguous(),
-                               cs_fc=(bp["s_fc"] * s2).contiguous(), cs_proj=(bp["s_proj"] * su).contiguous()))
-        self._fp8 = layers
-        return scales
+        self._fp8_amax, self._fp8_margin, self._fp8 = amax, float(margin), None
+        self._fp8_layers()
+        return (amax * margin / capi.FP8_MAX).clamp_min(1e-12)
+
+    def fp8_calibration(self):
+        """The calibrated activation maxima ([layers, 3] f32 on the host, or None) — store them next to a checkpoint and
+        hand them to `load_fp8_calibration` (they are not part of `state_dict`: the schema is the reference's)."""
+        return None if self._fp8_amax is None else self._fp8_amax.clone()
+
+    def load_fp8_calibration(self, amax, margin=1.0):
+        amax = torch.as_tensor(amax, dtype=torch.float32).cpu()
+        assert amax.shape == (self.layers, 3)
+        self._fp8_amax, self._fp8_margin, self._fp8 = amax, float(margin), None
+
+    def _fp8_layers(self):
+        """Per-layer activation scales x weight-row scales, rebuilt from the calibration whenever the prepared weights are."""
+        if self._fp8 is None:
+            assert self._fp8_amax is not None, "fp8 encoder: not calibrated"
+            p = self._prepare()
+            scales = (self._fp8_amax * self._fp8_margin / capi.FP8_MAX).clamp_min(1e-12)
+            layers = []
+            for l, bp in enumerate(p["blocks"]):
+                s1, s2, su = (float(v) for v in scales[l])
+                layers.append(dict(h1_inv=1.0 / s1, h2_inv=1.0 / s2, u_inv=1.0 / su, cs_qkv=(bp["s_qkv"] * s1).contiguous(),
+                                   cs_fc=(bp["s_fc"] * s2).contiguous(), cs_proj=(bp["s_proj"] * su).contiguous()))
+            self._fp8 = layers
+        return self._fp8
 
     def invalidate(self):
         """Call after changing parameters in place (load_state_dict and .to() do it themselves)."""
@@ -364,7 +385,9 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         makes the QKV epilogue also write the decoder operands; `kv_only` stops after the
         projection (nothing after it can reach an exported tensor)."""
         calib = getattr(self, "_calib", None)
-        f8 = self._fp8[bp["idx"]] if self.precision == "fp8" and calib is None else None
+        # fp8: chunks below the e4m3 kernel's smallest shape (1024 rows: 6 frames of ViT-B/16, 4 of ViT-L/14 — `ema_frame`
+        # batches, a short last clip) run the block on the bf16 operands that calibration keeps anyway
+        f8 = self._fp8_layers()[bp["idx"]] if self.precision == "fp8" and calib is None and M >= capi.FP8_MIN_ROWS else None
         so = self.stream_out
         sp = self.spare_cus if (self.spare_layers <= 0 or bp["idx"] < self.spare_layers) else 0
         sg = self.spare_gemms

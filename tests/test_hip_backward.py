@@ -337,11 +337,13 @@ def test_training_extras_match_reference(name):
     assert checked > 20
 
 
-def test_static_graphs_match_eager_training():
-    """Opt-in HIP-graph replay of the decoder's forward / backward kernels (`Detector.static_graphs`):
-    losses, gradients and two SGD steps equal the eager path bit for bit, and later steps see new inputs."""
+@pytest.mark.parametrize("name", ["small", "tiny_adapter_nln", "tiny_adapter_gl", "tiny_adapter_legacy"])
+def test_static_graphs_match_eager_training(name):
+    """Opt-in HIP-graph replay of the decoder's — and, with a trainable CompInvAdapter, the adapter's — forward / backward
+    kernels (`Detector.static_graphs`): losses, gradients and SGD steps equal the eager path bit for bit, and later
+    steps see new inputs."""
     import copy
-    case = build_case("small")
+    case = build_case(name)
     det_e = make_detector(case, "bf16")
     det_g = copy.deepcopy(det_e)
     det_g.static_graphs = True
@@ -368,12 +370,61 @@ def test_static_graphs_match_eager_training():
             assert torch.equal(ge[n], gg[n]), f"step {step}: gradient of {n} differs"
     for (n, pe), (_, pg) in zip(det_e.named_parameters(), det_g.named_parameters()):
         assert torch.equal(pe, pg), n
+    if det_g.adapter is not None:
+        from dfd_clip_amd import adapter as amod
+        assert len(amod._GRAPHS.get(det_g.adapter) or {}) == 1 and not det_g.adapter._graphs_failed, "the adapter must have replayed ONE graph"
     # eval / no_grad calls keep working (eager) on the graphed model
     det_g.eval()
     with torch.no_grad():
         a = det_g(x, [y], m, single_task=0)[1][0]
         b = det_e.eval()(x, [y], m, single_task=0)[1][0]
     assert torch.equal(a, b)
+
+
+def test_graphs_survive_an_epoch_boundary_and_an_eval_pass():
+    """train(full batch) -> train(short last batch) -> eval(other batch sizes) -> train(full batch): the K/V buffers of
+    the training signatures stay allocated at their addresses (inference keeps sets of its own), so the second epoch
+    replays the graphs captured in the first instead of capturing again or going eager; with more signatures than the
+    graph cache holds, the least recently used entry makes room (round 2 stopped capturing for good)."""
+    from dfd_clip_amd import decoder as dmod
+    case = build_case("small")
+    det = make_detector(case, "bf16")
+    det.static_graphs = True
+    x, m, y = case["x"].cuda(), case["m"].cuda(), case["y"].cuda()
+    big = (torch.cat([x, x.flip(0)]), torch.cat([m, m.flip(0)]), torch.cat([y, y.flip(0)]))  # "full" batch: 4 clips
+    opt = det.configure_optimizers(0.01)
+
+    def train_on(xs, ms, ys):
+        det.train()
+        opt.zero_grad(set_to_none=True)
+        losses, logits, other = det(xs, [ys], ms, train=True, single_task=0)
+        (losses[0].mean() + sum(other.values())).backward()
+        opt.step()
+        return logits[0].detach().clone()
+
+    def graphs():
+        return dmod._GRAPHS.get(det.decoder) or {}
+
+    train_on(*big)
+    train_on(x[:1], m[:1], y[:1])  # the epoch's short last batch
+    keys_epoch1 = list(graphs().keys())
+    assert len(keys_epoch1) == 2 and not det.decoder._graphs_failed
+    det.eval()
+    with torch.no_grad():
+        for n in (3, 1, 4):
+            det(big[0][:n], [big[2][:n]], big[1][:n], single_task=0)
+    a = train_on(*big)
+    train_on(x[:1], m[:1], y[:1])
+    assert list(graphs().keys())[-2:] == keys_epoch1 or set(graphs().keys()) == set(keys_epoch1), "epoch 2 must reuse epoch 1's graphs"
+    assert len(graphs()) == 2
+    # same step on a fresh eager model from the same parameters: graphs replayed on re-found buffers compute the same
+    det.decoder.max_graphs = 2
+    for n in (2, 3):  # two more signatures: the cache evicts instead of refusing
+        train_on(big[0][:n], big[1][:n], big[2][:n])
+    assert len(graphs()) == 2 and not det.decoder._graphs_failed
+    assert all(k not in graphs() for k in keys_epoch1)
+    b = train_on(*big)  # captured again after its eviction
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
 
 
 @pytest.mark.parametrize("graphs,name", [(False, "small"), (True, "small"), (False, "tiny_adapter_nln"), (False, "tiny_adapter_gl")])

@@ -357,6 +357,45 @@ def test_pingpong_gemm_ragged_panels_and_few_tiles(capi, M, N, K):
             assert torch.equal(c, want), (rep, opts)
 
 
+@pytest.mark.parametrize("M,N,K", [(1024 + 96, 768, 256), (30 * 196 * 3 + 17, 768, 256), (9000, 768, 768), (5000, 1024, 384)])
+@pytest.mark.parametrize("in_place,p", [(False, 0.0), (True, 0.0), (False, 0.5)])
+def test_pingpong_residual_pos_equals_relaunching(capi, M, N, K, in_place, p):
+    """The adapter's second Linear (reference models.py:795-875: C = residual + dropout(a . W^T) + pos[frame % T], rounded
+    once) on the ping-pong kernel — including its short-K form (K = 256: the shipped adapters' x) — against fp64 and,
+    bit for bit (same f32 sums, same mask, same single rounding), against the one-workgroup-per-tile kernel."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    P_, T_ = 196, 3
+    res = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+    pos = torch.randn(T_, N, device="cuda", generator=g)
+    rng = torch.tensor([12345, 7], device="cuda", dtype=torch.int64)
+    drop = capi.Dropout(rng, 1001, p) if p > 0 else None
+
+    def run():
+        c = res.clone() if in_place else torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        capi.gemm(a, w, c, None, capi.EPI_RESIDUAL_POS, pos=pos, tokens=P_ + 1, frames_per_clip=T_, residual=None if in_place else res, drop=drop)
+        return c
+
+    capi.gemm_set_variant(1)
+    try:
+        want = run()
+        assert capi.gemm_last_path() == 256
+    finally:
+        capi.gemm_set_variant(0)
+    if p == 0:
+        frame = (torch.arange(M, device="cuda") // P_) % T_
+        ref = res.double() + a.double() @ w.double().T + pos[frame].double()
+        assert_close(want, ref, 1e-4, 2 ** -8, "residual + pos")
+    else:
+        kept = (want.float() - res.float() - pos[(torch.arange(M, device="cuda") // P_) % T_]).abs() > 1e-2
+        assert 0.4 < kept.float().mean().item() < 0.6, "about half of the elements keep their (doubled) product"
+    for _ in range(2):
+        got = run()
+        assert capi.gemm_last_path() == 257
+        assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("res,patch,width", [(224, 16, 768), (224, 14, 1024)])
 def test_patch_embed_tuned_kernel(capi, res, patch, width):
     """PATCH_EMBED epilogue of the tuned kernel (M = frames*P >= 1024): conv1 + CLS row + positional embedding at
