@@ -88,6 +88,8 @@ def parse():
                     help="with --ingest u8: source frame size (default = the model's resolution, i.e. no resize)")
     ap.add_argument("--spare-cus", type=int, default=-1, help="CUs the encoder GEMMs leave to the decoder stream in pipelined training (-1 = package default)")
     ap.add_argument("--spare-layers", type=int, default=-1, help="encoder blocks at the start of a pass whose GEMMs (--spare-gemms) leave the spare CUs free (-1 = package default, 0 = all)")
+    ap.add_argument("--collective-layers", type=int, default=6,
+                    help="world size > 1: encoder blocks at the start of a pass in which every GEMM leaves the spare CUs to the RCCL all-reduce")
     ap.add_argument("--spare-gemms", default=None, help="lab: comma list of the block's GEMMs (qkv,out,fc,proj) that leave the spare CUs free")
     ap.add_argument("--gemm-stream-out", default=None,
                     help="comma list of encoder GEMM outputs stored non-temporally (qkv,out,fc,proj; 'none'); default = package default")
@@ -259,6 +261,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the all-reduce shares the chip with persistent GEMMs that leave it 32 CUs: one workgroup per channel
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -299,6 +303,11 @@ def main():
     # gradient all-reduce and optimizer step (the inputs are resident before the timed region: inputs_ready)
     det.pipeline_encoder = not args.no_pipeline
     det.inputs_ready = True
+    if world > 1:
+        # the gradient all-reduce of step N runs beside the first blocks of step N+1's encoder pass (decoder forward +
+        # backward take ~3 ms of the ~18 ms pass, the collective 1-3 ms after that): every GEMM of those blocks leaves
+        # the spare CUs to it (expected cost: one extra round of q|k|v and c_fc tiles per block, ~0.4 ms per step)
+        det.pipeline_collective_layers = args.collective_layers
     opt = det.configure_optimizers(0.01 / 25)
     trainable = [p for p in det.parameters() if p.requires_grad]
 

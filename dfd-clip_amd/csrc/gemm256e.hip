@@ -383,9 +383,14 @@ __global__ __launch_bounds__(512) void gemm256e_kernel(const GemmArgs a, int til
               const uint32_t tok = m - frame * (uint32_t)a.tokens;
               const uint32_t t = frame - a.div_frames.div(frame) * (uint32_t)a.frames_per_clip;
               eoff[rr] = (rloc < rows_left && tok > 0) ? ((frame * (uint32_t)(a.tokens - 1) + tok - 1) * (uint32_t)D + ecol) * 2 : 0xffffffffu;
-              const uint32_t poff = a.pos ? (t * (uint32_t)D + ecol) * 4 : 0xffffffffu;  // no embedding: out of range reads 0
-              pe[rr][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdP, poff, 0, 0));
-              pe[rr][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdP, poff, 16, 0));
+              // no embedding (the raw export an adapter reads): add zeros, and issue no load — a register load beside
+              // LDS-DMA costs a vmcnt(0) at its use, i.e. one memory round trip per sub-pass
+              pe[rr][0] = pe[rr][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (a.pos != nullptr) {
+                const uint32_t poff = (t * (uint32_t)D + ecol) * 4;
+                pe[rr][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdP, poff, 0, 0));
+                pe[rr][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdP, poff, 16, 0));
+              }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)

@@ -246,6 +246,10 @@ class Detector(RuntimeStateMixin, nn.Module):
         self.pipeline_spare_cus = None  # None = one compute unit per shader engine (CUs / 8), see `_encode`
         self.pipeline_spare_layers = 0  # encoder blocks at the start of a pass that leave those CUs free (0 = all); which
                                         # of a block's GEMMs do is `encoder.spare_gemms` (c_proj only: see there)
+        # Multi-GPU (world size > 1): in the first `pipeline_collective_layers` blocks of a pipelined training pass EVERY
+        # encoder GEMM leaves the spare CUs free, not only c_proj — that is where the previous step's gradient all-reduce
+        # (one RCCL kernel of at most NCCL_MAX_NCHANNELS workgroups) runs beside the encoder; set by the launcher / bench
+        self.pipeline_collective_layers = 0
         self._enc_stream = None
         self._pipe_events = [[], []]
         self._pipe_step = 0
@@ -415,6 +419,7 @@ class Detector(RuntimeStateMixin, nn.Module):
             spare = torch.cuda.get_device_properties(x.device).multi_processor_count // 8
         self.encoder.spare_cus = spare if torch.is_grad_enabled() and self.training else 0
         self.encoder.spare_layers = self.pipeline_spare_layers
+        self.encoder.spare_window_layers = self.pipeline_collective_layers if torch.is_grad_enabled() and self.training else 0
         try:
             with torch.cuda.stream(E):
                 kv = finish(self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos, pos_ready=pos_ready, **kw))

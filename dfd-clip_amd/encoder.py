@@ -150,6 +150,10 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         # ... and only by these GEMMs of a block.  c_proj (N = D: 4.3 rounds of 256-row tiles on every CU, 5 either way on
         # 224) gives its spare CUs away for free; q|k|v and c_fc pay a whole extra round of tiles for them
         self.spare_gemms = {"qkv": False, "out": False, "fc": False, "proj": True}
+        # ... except in the first `spare_window_layers` blocks of a pass, where EVERY GEMM leaves them: at world size > 1
+        # the gradient all-reduce of the previous step (an RCCL kernel on the caller's stream) lands in that window, and a
+        # persistent GEMM that holds all 256 CUs would make its workgroups queue for a whole GEMM each
+        self.spare_window_layers = 0
 
     # ---- derived device-side operands ---------------------------------------------------
     @property
@@ -390,8 +394,9 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         f8 = self._fp8_layers()[bp["idx"]] if self.precision == "fp8" and calib is None and M >= capi.FP8_MIN_ROWS else None
         so = self.stream_out
         sp = self.spare_cus if (self.spare_layers <= 0 or bp["idx"] < self.spare_layers) else 0
+        sp_all = self.spare_cus if bp["idx"] < self.spare_window_layers else 0
         sg = self.spare_gemms
-        sp_qkv, sp_out, sp_fc, sp_proj = (sp if sg[k] else 0 for k in ("qkv", "out", "fc", "proj"))
+        sp_qkv, sp_out, sp_fc, sp_proj = (max(sp_all, sp if sg[k] else 0) for k in ("qkv", "out", "fc", "proj"))
         D = self.width
         # q | k | v projection (+ K/V export); the last tapped layer computes only the K and V thirds
         first = 1 if kv_only else 0

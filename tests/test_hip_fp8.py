@@ -201,8 +201,9 @@ def test_fp8_encoder_close_to_bf16(name):
     assert torch.isfinite(l8).all()
     assert rel < 0.08, "exported keys drift more than e4m3 quantisation explains"
     # 24 random-weight layers (vitl14) carry the per-layer e4m3 noise (2^-4 per element) further than 3 do (small):
-    # measured 3.0e-1 / 2.8e-2 on the norm-5 logits; the AUROC / rank test below is the acceptance criterion
-    assert dl < (0.5 if name == "vitl14" else 0.1)
+    # measured 3.0e-1 / 2.8e-2 on the norm-5 logits (a common shift, see FP8_L14_* below); the AUROC / rank tests are the
+    # acceptance criterion
+    assert dl < (0.4 if name == "vitl14" else 0.06)
 
 
 def test_fp8_small_chunks_and_calibration_survival():
@@ -264,3 +265,86 @@ def test_fp8_auroc_parity_vs_bf16():
     print(f"AUROC bf16 {a16:.4f} fp8 {a8:.4f}  max|dp| {np.abs(out['bf16'] - out['fp8']).max():.3e}  spearman {sp:.5f}")
     assert abs(a8 - a16) <= 1e-3
     assert sp > 0.99
+
+
+def test_fp8_auroc_parity_vitl14():
+    """configs[4] on the architecture it names (ViT-L/14: 24 layers, width 1024, 16 heads, 257 tokens; every second layer
+    tapped): 256 synthetic clips of 2 frames, labels Bernoulli(0.5) seed 7, dummy [0, 1] pair appended — AUROC of the
+    fp8 path against the bf16 path and Spearman rank correlation of p(real); calibration on the first 16 clips.  Also
+    prints the fp8 / bf16 logits of the committed `vitl14` case against the reference's own fp32 logits."""
+    from tests.cases import build_case, load_golden
+    case = build_case("vitl14")
+    T, res, n_clips = case["T"], case["res"], 256
+    rng = np.random.default_rng(4321)
+    x = torch.from_numpy(rng.standard_normal((n_clips, T, 3, res, res), dtype=np.float32))
+    m = torch.ones(n_clips, T, dtype=torch.bool)
+    m[3::7, T - 1:] = False
+    y = np.random.default_rng(7).integers(0, 2, n_clips)
+    out, gold = {}, {}
+    for precision in ("bf16", "fp8"):
+        det = _make(case, precision)
+        if precision == "fp8":
+            det.calibrate_fp8(x[:16].cuda())
+        p, lg = [], []
+        with torch.no_grad():
+            for i in range(0, n_clips, 32):
+                logits, _ = det.predict(x[i:i + 32].cuda(), m[i:i + 32].cuda())
+                p.append(logits[0].softmax(dim=-1)[:, 1].cpu())
+                lg.append(logits[0].float().cpu())
+            gold[precision] = det.predict(case["x"].cuda(), case["m"].cuda())[0][0].float().cpu()
+        out[precision] = (torch.cat(p).numpy(), torch.cat(lg))
+        del det
+        torch.cuda.empty_cache()
+    ref = torch.from_numpy(load_golden("vitl14")["logits"]).float().view_as(gold["bf16"])
+    a16, a8 = _auroc(y, out["bf16"][0]), _auroc(y, out["fp8"][0])
+    sp = _spearman(out["bf16"][0], out["fp8"][0])
+    dl = (out["bf16"][1] - out["fp8"][1]).abs().max().item()
+    print(f"ViT-L/14: AUROC bf16 {a16:.4f} fp8 {a8:.4f}  max|dp| {np.abs(out['bf16'][0] - out['fp8'][0]).max():.3e}  spearman {sp:.5f}  "
+          f"max|dlogit| {dl:.3e}; vs the reference's fp32 logits: bf16 {(gold['bf16'] - ref).abs().max().item():.3e}, "
+          f"fp8 {(gold['fp8'] - ref).abs().max().item():.3e}")
+    assert abs(a8 - a16) <= FP8_L14_AUROC_BAR
+    assert sp > FP8_L14_SPEARMAN_BAR
+    assert dl < FP8_L14_LOGIT_BAR
+
+
+# Bars of the ViT-L/14 acceptance test, from what MI355X measured (profiles/r03_fp8_vitl14_acceptance.txt): AUROC 0.5340
+# (bf16) vs 0.5334-0.5359 (fp8, by calibration set and margin: neither matters, e4m3 is a floating-point format), Spearman
+# 0.9940-0.9946, |dlogit| max 0.62-0.65 / mean 0.29-0.30 on norm-5 logits.  The drift is mostly a COMMON shift (max / mean
+# ~ 2, independent noise would give ~ 4): W8A8 e4m3 puts ~3.6 % rms noise on every projection output, and the second-order
+# bias of the non-linearities under that noise (E[gelu(x + n)] - gelu(x) = gelu''(x) var(n) / 2) adds up linearly over 24
+# randomly initialised layers where the noise itself adds up as a square root.  A rank statistic ignores a common shift:
+# Spearman stays above 0.99; AUROC moves by single near-tie swaps (1 / (n_pos n_neg) = 6e-5 each).
+FP8_L14_AUROC_BAR = 3e-3
+FP8_L14_SPEARMAN_BAR = 0.99
+FP8_L14_LOGIT_BAR = 0.8
+
+
+def test_full_size_properties_vitl14_fp8_b16_t30():
+    """configs[4] at full size (ViT-L/14, 16 clips x 30 frames, e4m3 operands, static scales): the size-independent
+    properties of the bf16 full-size tests — clips independent (batch permutation permutes the logits bit for bit), two
+    frame chunks equal one pass, padded frames without influence, logits of norm 5."""
+    from dfd_clip_amd.detector import Detector
+    from dfd_clip_amd.weights import random_state_dict
+    from tests.cases import make_config
+    cfg = make_config("ViT-L/14", decode_mode="stride", decode_stride=2)
+    B, T = 16, 30
+    det = Detector(cfg, T, None, precision="fp8")
+    det.load_state_dict(random_state_dict(cfg, T, seed=0))
+    det = det.cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(13)
+    x = torch.randn(B, T, 3, 224, 224, device="cuda", generator=g)
+    m = torch.ones(B, T, dtype=torch.bool, device="cuda")
+    m[5, 11:] = False
+    with torch.no_grad():
+        det.calibrate_fp8(x[:2])
+        base = det.predict(x, m)[0][0].clone()
+        assert torch.isfinite(base).all()
+        np.testing.assert_allclose(base.norm(dim=-1).cpu().numpy(), 5.0, atol=1e-4)
+        perm = torch.randperm(B, device="cuda", generator=g)
+        assert torch.equal(det.predict(x[perm].contiguous(), m[perm].contiguous())[0][0], base[perm]), "clips are not independent"
+        det.encoder.frame_chunk = 5 * T
+        assert torch.equal(det.predict(x, m)[0][0], base), "frame chunking changed the result"
+        det.encoder.frame_chunk = 0
+        x2 = x.clone()
+        x2[5, 11:] = 100.0 * torch.randn_like(x2[5, 11:])
+        assert torch.equal(det.predict(x2, m)[0][0], base), "a padded frame influenced its clip"
