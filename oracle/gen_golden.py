@@ -70,6 +70,7 @@ def load_reference():
         return mod
 
     cm = _load("refsrc.clip_model", REF + "/src/clip/model.py")
+    sys.modules["refsrc.clip_model"] = cm
 
     def load(name, *a, **k):
         r, p, w, l, h, o = ARCHS[name]
@@ -133,6 +134,12 @@ CASES = {
     "vitb16_cfg1": ("ViT-B/16", 2, 8, dict(decode_mode="index", decode_indices=[6, 7, 8, 9, 10, 11]), "slices"),
     # BASELINE configs[3]'s architecture (width 1024, 24 layers, 16 heads, 257 tokens, patch K = 588), every other layer tapped
     "vitl14": ("ViT-L/14", 2, 2, dict(decode_mode="stride", decode_stride=2), "slices"),
+    # GELU-first adapters at the real width (768 -> 256 -> 768 on ViT-B/16 keys / values, 1 clip x 2 frames, layers 10 and
+    # 11 tapped): the LayerNorm behind the GELU normalises 256 values per row here, not the tiny model's 32
+    "vitb16_adapter_gl": ("ViT-B/16", 1, 2, dict(decode_mode="index", decode_indices=[10, 11], adapter__type="normal",
+                                                 adapter__frozen=0, adapter__struct={"type": "768-x-768", "x": 256}), "light"),
+    "vitb16_adapter_legacy": ("ViT-B/16", 1, 2, dict(decode_mode="index", decode_indices=[10, 11], adapter__type="normal",
+                                                     adapter__frozen=0, adapter__struct={"type": "legacy-768-x-768", "x": 256}), "light"),
     # training-mode extras (reference models.py:511-544, :572-578, :598-736)
     "tiny_ema": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], op_mode__ema_frame=0.3,
                                     op_mode__temporal_position=0), "light"),
@@ -241,8 +248,36 @@ def run_case(name, mm, Acc, to_cn):
           f"-> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def run_loader_fixture(arch="tiny"):
+    """Checkpoint-loader pin: the reference's own `build_model` (src/clip/model.py:453-496: architecture
+    from tensor shapes, `convert_weights` to fp16, strict load) followed by `.visual.float()` (src/models.py:440) on the
+    seeded synthetic checkpoint of tests/cases.py — the resulting visual-tower tensors and the inferred architecture."""
+    from tests.cases import synthetic_clip_checkpoint
+    cm = sys.modules["refsrc.clip_model"]
+    out = {}
+    for tag, dtype in (("fp32ckpt", None), ("fp16ckpt", torch.float16)):
+        sd = synthetic_clip_checkpoint(arch, seed=3, dtype=dtype)
+        model = cm.build_model(dict(sd))
+        vis = model.visual.float()
+        v = vis
+        out[f"{tag}.arch"] = np.asarray([v.input_resolution, v.conv1.kernel_size[0], v.conv1.out_channels, len(v.transformer.resblocks),
+                                         v.transformer.resblocks[0].attn.n_head, v.output_dim])
+        for k, t in vis.state_dict().items():
+            a = t.detach().numpy().copy()
+            if dtype is torch.float16:  # every value came out of an fp16 tensor: stored in half the bytes, exactly
+                assert np.array_equal(a.astype(np.float16).astype(np.float32), a), k
+                a = a.astype(np.float16)
+            out[f"{tag}.{k}"] = a
+    path = os.path.join(ROOT, "tests", "golden", f"clip_loader_{arch}.npz")
+    np.savez_compressed(path, **out)
+    print(f"loader fixture ({arch}): arch {out['fp32ckpt.arch'].tolist()}, {len(out)} entries -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     mm, Acc, to_cn = load_reference()
-    for c in (sys.argv[1:] or list(CASES)):
-        run_case(c, mm, Acc, to_cn)
+    for c in (sys.argv[1:] or list(CASES) + ["loader"]):
+        if c == "loader":
+            run_loader_fixture("tiny")
+        else:
+            run_case(c, mm, Acc, to_cn)

@@ -30,6 +30,12 @@ CASES = {
     "small14": ("small14", 2, 3, dict(decode_mode="index", decode_indices=[0, 1])),
     "vitb16_cfg1": ("ViT-B/16", 2, 8, dict(decode_mode="index", decode_indices=[6, 7, 8, 9, 10, 11])),
     "vitl14": ("ViT-L/14", 2, 2, dict(decode_mode="stride", decode_stride=2)),
+    # GELU-first adapters at the real width (768 -> 256 -> 768 on ViT-B/16 keys / values, 1 clip x 2 frames, layers 10 and
+    # 11 tapped): the LayerNorm behind the GELU normalises 256 values per row here, not the tiny model's 32
+    "vitb16_adapter_gl": ("ViT-B/16", 1, 2, dict(decode_mode="index", decode_indices=[10, 11], adapter__type="normal",
+                                                 adapter__frozen=0, adapter__struct={"type": "768-x-768", "x": 256})),
+    "vitb16_adapter_legacy": ("ViT-B/16", 1, 2, dict(decode_mode="index", decode_indices=[10, 11], adapter__type="normal",
+                                                     adapter__frozen=0, adapter__struct={"type": "legacy-768-x-768", "x": 256})),
     "tiny_ema": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], op_mode__ema_frame=0.3,
                                     op_mode__temporal_position=0)),
     "tiny_rank": ("tiny", 2, 4, dict(decode_mode="index", decode_indices=[0, 1], train_mode__temporal="ranking")),
@@ -79,3 +85,30 @@ def oracle_kwargs(case):
 def load_golden(name):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")
     return np.load(path, allow_pickle=False)
+
+
+def synthetic_clip_checkpoint(arch="tiny", seed=3, dtype=None):
+    """A complete synthetic CLIP state_dict in the published key layout (`visual.`-prefixed ViT tower of `arch` plus a
+    one-block text tower of width 64, the keys reference clip/model.py:453-496 `build_model` insists on), fp32, seeded.
+    `oracle/gen_golden.py loader` ran the reference's own `build_model(sd).visual.float()` on exactly this dictionary to
+    produce tests/golden/clip_loader_<arch>.npz; tests/test_host_cpu.py feeds it to `load_clip_visual`."""
+    import torch
+    from dfd_clip_amd.weights import _fill, encoder_schema
+    rng = np.random.default_rng(seed)
+    sd = {"visual." + k: _fill(rng, k, shp) for k, shp in encoder_schema(arch).items()}
+    tw, ctx, vocab, embed = 64, 4, 16, ARCHS[arch][5]
+
+    def rnd(*shape, scale=0.05):
+        return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))
+
+    sd.update({"token_embedding.weight": rnd(vocab, tw), "positional_embedding": rnd(ctx, tw), "text_projection": rnd(tw, embed),
+               "logit_scale": torch.tensor(2.5), "ln_final.weight": 1 + rnd(tw), "ln_final.bias": rnd(tw)})
+    pre = "transformer.resblocks.0."
+    sd.update({pre + "attn.in_proj_weight": rnd(3 * tw, tw), pre + "attn.in_proj_bias": rnd(3 * tw),
+               pre + "attn.out_proj.weight": rnd(tw, tw), pre + "attn.out_proj.bias": rnd(tw),
+               pre + "ln_1.weight": 1 + rnd(tw), pre + "ln_1.bias": rnd(tw), pre + "ln_2.weight": 1 + rnd(tw), pre + "ln_2.bias": rnd(tw),
+               pre + "mlp.c_fc.weight": rnd(4 * tw, tw), pre + "mlp.c_fc.bias": rnd(4 * tw),
+               pre + "mlp.c_proj.weight": rnd(tw, 4 * tw), pre + "mlp.c_proj.bias": rnd(tw)})
+    if dtype is not None:
+        sd = {k: (v.to(dtype) if v.is_floating_point() and v.dim() > 0 else v) for k, v in sd.items()}
+    return sd

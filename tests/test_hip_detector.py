@@ -18,8 +18,10 @@ BF16_TOL = 5e-2
 # divides by their (small) spread, which amplifies the bf16 rounding of the K/V operands about 4x more than
 # the LayerNorm-first structs (measured 5.5e-2 with the projection kept in f32, fp32 path 1e-5)
 BF16_TOL_CASE = {"tiny_adapter_gl": 1e-1, "tiny_adapter_legacy": 1e-1}
+# ... and the same structs at the real width (ViT-B/16 keys, 768 -> 256 -> 768: the LayerNorm normalises 256 values per row)
+# stay inside the general bar: `vitb16_adapter_gl` / `_legacy` below
 SUPPORTED = ["tiny", "tiny_stride", "tiny_nopos", "tiny_augq", "small", "small14", "tiny_adapter_nln", "tiny_adapter_ln", "tiny_adapter_gl", "tiny_adapter_legacy",
-             "tiny_global", "tiny_attnmode"]
+             "tiny_global", "tiny_attnmode", "vitb16_adapter_gl", "vitb16_adapter_legacy"]
 
 
 def make_detector(case, precision):
@@ -157,7 +159,8 @@ def test_vitl14_matches_reference(precision):
                 np.testing.assert_allclose(enc[l][key][i, rows].float().cpu().numpy(), g[f"enc{l}_{key}_f{fr}"], atol=tol_kv, rtol=0)
 
 
-BF16_GOLDEN_CASES = ["small", "small14", "vitb16_cfg1", "vitl14", "tiny_adapter_nln", "tiny_adapter_ln", "tiny_adapter_gl"]
+BF16_GOLDEN_CASES = ["small", "small14", "vitb16_cfg1", "vitl14", "tiny_adapter_nln", "tiny_adapter_ln", "tiny_adapter_gl", "vitb16_adapter_gl",
+                     "vitb16_adapter_legacy"]
 
 
 @pytest.mark.parametrize("name", BF16_GOLDEN_CASES)
@@ -167,7 +170,8 @@ def test_bf16_path_against_reference_bf16_run(name):
     random-weight cases the reference's bf16 run is itself 7e-3 .. 1e-1 away from its fp32 run (stored in the
     fixtures, printed here), so two correct bf16 implementations cannot agree more tightly than that.  Bars:
     (1) this path is no further from the reference's fp32 logits than the reference's own bf16 run is, plus
-    1e-2; (2) it is within that deviation + its own of the reference's bf16 logits (both printed)."""
+    1e-2; (2) it is no further from the reference's bf16 logits than twice that run's own deviation, plus 1e-2
+    (two bf16 evaluations of one fp32 function, each within `ref_dev`-like rounding of it; both printed)."""
     case = build_case(name)
     g = load_golden(name)
     det = make_detector(case, "bf16")
@@ -182,7 +186,7 @@ def test_bf16_path_against_reference_bf16_run(name):
     # the GELU-then-LayerNorm adapter on the 32-wide tiny model amplifies the bf16 rounding of its K/V operands
     # (see BF16_TOL_CASE): its documented bar stays 1e-1 against the fp32 logits
     assert d32 <= max(ref_dev + 1e-2, BF16_TOL_CASE.get(name, 0.0))
-    assert d16 <= ref_dev + d32 + 1e-6
+    assert d16 <= max(2 * ref_dev + 1e-2, BF16_TOL_CASE.get(name, 0.0))
     if name in ("vitb16_cfg1", "vitl14", "small", "small14"):
         rows = list(g["slice_rows"])
         n = case["B"] * case["T"]

@@ -1,5 +1,7 @@
 """CPU checks of host-side logic: config node, weight schema / seed recipe, Detector
 construction and state_dict schema, layer-index resolution."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -205,6 +207,28 @@ def test_load_clip_visual_fp32_checkpoint_takes_the_fp16_round_trip(tmp_path):
         rounded += int(halved and not torch.equal(want, src))
     assert rounded >= 4 * 2 + 2  # the round trip really changed those tensors
     assert torch.equal(got["transformer.resblocks.0.attn.in_proj_weight"], sd["visual.transformer.resblocks.0.attn.in_proj_weight"])
+
+
+@pytest.mark.parametrize("tag,dtype", [("fp32ckpt", None), ("fp16ckpt", torch.float16)])
+def test_load_clip_visual_equals_the_references_build_model(tmp_path, golden_dir, tag, dtype):
+    """Pinned by the reference itself: tests/golden/clip_loader_tiny.npz holds what the reference's `build_model(sd)`
+    (src/clip/model.py:453-496, incl. `convert_weights`) followed by `.visual.float()` (src/models.py:440) made of the
+    seeded synthetic checkpoint of tests/cases.py (oracle/gen_golden.py loader).  `load_clip_visual` on the same
+    checkpoint: same architecture, every tensor bit for bit."""
+    from dfd_clip_amd.detector import load_clip_visual
+    from tests.cases import synthetic_clip_checkpoint
+    build()
+    g = np.load(os.path.join(golden_dir, "clip_loader_tiny.npz"), allow_pickle=False)
+    sd = synthetic_clip_checkpoint("tiny", seed=3, dtype=dtype)
+    path = str(tmp_path / "clip.pt")
+    torch.save(sd, path)
+    vit = load_clip_visual(path, "fp32")
+    assert [vit.input_resolution, vit.patch_size, vit.width, vit.layers, vit.heads, vit.output_dim] == g[tag + ".arch"].tolist()
+    got = vit.state_dict()
+    want = {k[len(tag) + 1:]: g[k] for k in g.files if k.startswith(tag + ".") and not k.endswith(".arch")}
+    assert set(got) == set(want)
+    for k, v in got.items():
+        assert v.dtype == torch.float32 and np.array_equal(v.numpy(), want[k].astype(np.float32)), k
 
 
 def test_load_clip_visual_rejects_torchscript_archive_with_instructions(tmp_path):
