@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--spare-gemms", default=None, help="lab: comma list of the block's GEMMs (qkv,out,fc,proj) that leave the spare CUs free")
     ap.add_argument("--gemm-stream-out", default=None,
                     help="comma list of encoder GEMM outputs stored non-temporally (qkv,out,fc,proj; 'none'); default = package default")
+    ap.add_argument("--gemm-dynamic", action="store_true",
+                    help="A/B: the persistent GEMM hands out the tiles after a workgroup's first from per-XCD counters instead of dealing them statically")
     ap.add_argument("--adapter", default="none", choices=["none", "nln", "z0", "ln"],
                     help="CompInvAdapter 768-x-768-<struct>, x = 256 (every configs/deepfake/*.yaml enables one); default none = headline")
     return ap.parse_args()
@@ -275,6 +277,8 @@ def main():
 
     from dfd_clip_amd import capi
     from dfd_clip_amd.weights import ARCHS
+    if args.gemm_dynamic:
+        capi.gemm_set_variant(3)
     det, cfg, sd, layers = build_model(args, device)
     res, patch, width, _, heads, _ = ARCHS[args.arch]
     B, T = args.clips, args.frames

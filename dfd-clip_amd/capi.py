@@ -309,7 +309,8 @@ def gemm_fp8(a, w, c, col_scale, bias=None, epilogue=EPI_BIAS, m=None, out_inv_s
 
 
 def gemm_set_variant(variant):
-    """0 = every GEMM kernel eligible (default); 1 = skip the ping-pong kernel (tests / A-B runs).  Returns the previous value."""
+    """0 = every GEMM kernel eligible, tiles dealt statically (default); 1 = skip the ping-pong kernel (tests / A-B runs);
+    3 = the ping-pong kernel hands its tiles out dynamically (per-XCD counters).  Per thread.  Returns the previous value."""
     return load_library().dfd_gemm_set_variant(int(variant))
 
 

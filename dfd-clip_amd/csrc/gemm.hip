@@ -343,6 +343,7 @@ extern "C" int dfd_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
   if (ab_dtype == DFD_BF16) {
     // a q|k|v projection without an export is a plain biased store
     const int epi_p = epilogue == DFD_EPI_QKV_EXPORT && a.k_export == nullptr ? DFD_EPI_BIAS : epilogue;
+    a.no_dynamic = g_gemm_variant != 3;
     int rc = g_gemm_variant == 1 ? 1 : dfd_gemm256e_try(a, c_dtype, epi_p, st);  // ping-pong K loop (K a multiple of 128, >= 384)
     if (rc == 0) g_last_path = 257;
     if (rc <= 0) return rc;
@@ -375,6 +376,7 @@ extern "C" int dfd_gemm_fp8(const void* A, int64_t lda, const void* W, int64_t l
   { const int rc = fill_extra(a, epilogue, extra, c_dtype, ldc, M, N); if (rc != DFD_OK) return rc; }
   if (M == 0) return DFD_OK;
   const int epi_p = epilogue == DFD_EPI_QKV_EXPORT && a.k_export == nullptr ? DFD_EPI_BIAS : epilogue;
+  a.no_dynamic = g_gemm_variant != 3;
   int rc = g_gemm_variant == 1 ? 1 : dfd_gemm256e_f8_try(a, c_dtype, epi_p, static_cast<hipStream_t>(stream));
   if (rc == 1) rc = dfd_gemm256p_f8_try(a, c_dtype, epi_p, static_cast<hipStream_t>(stream));
   if (rc == 1) {

@@ -26,9 +26,20 @@
 //   * a store whose lanes are ALL out of range is dropped by the buffer unit and retires at once, ahead of older loads:
 //     a wait that counts such stores waits for nothing.  A wave therefore counts its previous epilogue's stores only
 //     when every one of them was a real store (all of its rows inside M); otherwise it waits as if there were none.
+// Tiles after a workgroup's first are handed out dynamically WITHIN an XCD: the workgroups that share an XCD label
+// (blockIdx & 7) draw the label's tile list — the same XCD-contiguous runs the static order gave them — from one counter.
+// A workgroup that starts late or runs slowly because another stream's kernels hold its CU (the decoder's kernels beside a
+// pipelined encoder pass, an RCCL all-reduce) then simply takes fewer tiles, instead of making the whole launch wait for
+// its full share.  One returning atomic per tile, issued by wave 0 at the top of a tile for the tile after it and counted
+// in that wave's waits; the counters are monotonic (the launcher passes the value each will have when the launch
+// starts), so nothing has to be reset.  Launches that are being captured into a HIP graph keep the static order.
+//
 // Measured on MI355X against gemm256p (same process, interleaved; profiles/r03_gemm_pingpong_lab.txt): c_fc 0.411 ->
 // 0.398-0.403 ms, q|k|v 0.285-0.292 -> 0.272-0.279, c_proj 0.388-0.395 -> 0.343-0.349, 8192^3 1,434 -> 1,590 TFLOP/s;
 // bit-identical to it on every shape; without the stagger (same code, groups in lockstep) 10-15 % slower.
+#include <mutex>
+#include <unordered_map>
+
 #include "gemm256p_common.hpp"
 
 namespace {
@@ -71,6 +82,9 @@ __global__ __launch_bounds__(512) void gemm256e_kernel(const GemmArgs a, int til
   };
   const v4i srdB = words(a.bias ? a.bias : reinterpret_cast<const float*>(a.W), a.bias ? a.N * 4 : 0);
   [[maybe_unused]] const v4i srdS = words(F8 ? a.col_scale : reinterpret_cast<const float*>(a.W), F8 ? a.N * 4 : 0);
+  // dynamic hand-out: this label's workgroups (cnt_x of them, at positions off_x .. of every round) share counter xcd
+  const int cnt_x = q8 + (xcd < r8 ? 1 : 0), off_x = pos - (bid >> 3);
+  const v4i srdT = words(reinterpret_cast<const float*>(a.sched ? a.sched : reinterpret_cast<const uint32_t*>(a.W)), a.sched ? 8 * 128 : 0);
 
   // ---- LDS-DMA staging: wave w fills LDS rows [16w, 16w+16) of a unit in two 8-row pieces (1 KiB each) -------------
   // vA[ha][q] / vW[hb]: per-lane byte offsets of the pieces, for the tile whose units of that kind are being REQUESTED.
@@ -208,10 +222,34 @@ __global__ __launch_bounds__(512) void gemm256e_kernel(const GemmArgs a, int til
     }
   }
 
+  const int nk_ = a.K / (F8 ? 128 : TK);
+  // (the short-K form needs the next tile before a draw could return; the e4m3 forms have no register left for the draw)
+  const bool dyn = !F8 && a.sched != nullptr && nk_ >= 6;
+  const bool drawer = dyn && wave == 0;
   for (;;) {
-    const int nidx = idx + G;
-    const bool has_next = nidx < ntiles;
-    const Tile nxt = has_next ? decode_tile(nidx, tiles_m, tiles_n, TMU) : cur;
+    // the tile after this one: known at once when tiles are dealt statically; drawn from the label's counter otherwise
+    // (requested here by wave 0, published through LDS behind the K loop's first plain wait, read by every wave after the
+    // second K tile: `draw_next` below)
+    int nidx = idx + G;
+    bool has_next = nidx < ntiles;
+    Tile nxt = has_next ? decode_tile(nidx, tiles_m, tiles_n, TMU) : cur;
+    uint32_t drawn = 1;
+    if (drawer) {
+      // ONE lane adds: EXEC is narrowed to lane 0 around the instruction.  (Steering the other lanes out of range with an
+      // offset of ~0, as the masked stores do, is not an option here: an atomic with such an offset faulted — 'memory
+      // aperture violation' — instead of being dropped.)
+      const uint32_t coff = (uint32_t)(xcd * 128);
+      uint64_t saved_exec;
+      asm volatile(
+          "s_mov_b64 %1, exec\n\t"
+          "s_mov_b64 exec, 1\n\t"
+          "s_nop 4\n\t"
+          "buffer_atomic_add %0, %2, %3, 0 offen sc0\n\t"
+          "s_mov_b64 exec, %1"
+          : "+v"(drawn), "=&s"(saved_exec)
+          : "v"(coff), "s"(srdT)
+          : "memory");
+    }
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -271,11 +309,30 @@ __global__ __launch_bounds__(512) void gemm256e_kernel(const GemmArgs a, int til
         constexpr bool stores_young = HEAD < 2 && 4 * HEAD + p <= DEPTH - 2;
         constexpr bool cv_young = END <= 1 && 4 * (1 - END) + p <= DEPTH - 2;
         if constexpr (stores_young) {  // (never together with the column-vector window: nk >= 6)
-          if (s_prev == 0) wait_vm<NB>();
-          else if (EPI != DFD_EPI_QKV_EXPORT || s_prev == S1) wait_vm<NB + S1>();
-          else wait_vm<NB + S2>();
+          // ... and wave 0's draw of the next tile, issued at the top of the tile: as young as the stores
+          if (drawer) {
+            if (s_prev == 0) wait_vm<NB + 1>();
+            else if (EPI != DFD_EPI_QKV_EXPORT || s_prev == S1) wait_vm<NB + S1 + 1>();
+            else wait_vm<NB + S2 + 1>();
+          } else {
+            if (s_prev == 0) wait_vm<NB>();
+            else if (EPI != DFD_EPI_QKV_EXPORT || s_prev == S1) wait_vm<NB + S1>();
+            else wait_vm<NB + S2>();
+          }
         } else {
           wait_vm<NB + (cv_young ? NCV : 0)>();
+        }
+        if constexpr (HEAD < 2 && 4 * HEAD + p == DEPTH - 1) {
+          // first wait that no longer skips the draw: it has returned.  Publish it (wave 0's staging, beyond the parked
+          // column vectors); the other waves read it several barriers later
+          // (explicit DS instructions on the LDS byte address: a volatile access through the generic pointer makes the
+          // compiler fall back to FLAT instructions for this and every other staging access — those count in vmcnt too)
+          if (drawer) {
+            const uint32_t slot_addr = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + RING + 1024);
+            asm volatile("" : "+v"(drawn));  // (the compiler believes it was written when the atomic was issued)
+            const uint32_t lane0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);  // only lane 0 drew; every lane stores its value
+            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(slot_addr), "v"(lane0) : "memory");
+          }
         }
         if constexpr (END <= 1 && 4 * (1 - END) + p == DEPTH - 1) {
           park_col_vectors();  // the column vectors have landed
@@ -319,6 +376,17 @@ __global__ __launch_bounds__(512) void gemm256e_kernel(const GemmArgs a, int til
     } else {
       ktile(0, C0{}, C0{}, C4{});
       ktile(1, C1{}, C1{}, C4{});
+      if (dyn) {  // draw_next: the n-th tile drawn on this label is position n % cnt_x of its round 1 + n / cnt_x
+        uint32_t n;
+        const uint32_t slot_addr = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + RING + 1024);
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(n) : "v"(slot_addr) : "memory");
+        n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n) - a.sched_base[xcd];
+        const uint32_t r = n / (uint32_t)cnt_x;
+        has_next = r < (uint32_t)(ntiles / G + 1);  // (also keeps a counter that ran away from overflowing the index)
+        nidx = (int)((r + 1) * (uint32_t)G + (uint32_t)off_x + (n - r * (uint32_t)cnt_x));
+        has_next = has_next && nidx < ntiles;
+        nxt = has_next ? decode_tile(nidx, tiles_m, tiles_n, TMU) : cur;
+      }
       for (int kt = 2; kt < nk - 4; kt += 2) {
         ktile(kt, C0{}, C2{}, C4{});
         ktile(kt + 1, C1{}, C2{}, C4{});
@@ -575,8 +643,62 @@ __global__ __launch_bounds__(512) void gemm256e_kernel(const GemmArgs a, int til
   if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with the second group's extra barrier
 }
 
+// ---- host side of the dynamic hand-out -------------------------------------------------------------------------------
+// One set of eight counters per stream (launches of one stream run one after the other, so they can share a set; launches
+// of different streams may overlap and must not).  The counters only ever grow: a launch is told the value each will hold
+// when it starts, which the host knows because a launch with grid G over `ntiles` tiles adds exactly (its workgroups'
+// first tiles) + (the tiles drawn) = one draw per tile processed to the label's counter.
+struct SchedSlot {
+  uint32_t* dev = nullptr;
+  uint32_t base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+bool sched_prepare(GemmArgs& a, hipStream_t st, int grid, int64_t ntiles) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, SchedSlot> slots;
+  static uint32_t* pool = nullptr;
+  static int used = 0;
+  constexpr int MAX_SLOTS = 64;
+  a.sched = nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return true;  // a captured launch is replayed with the same arguments: static order
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = slots.find(st);
+  if (it == slots.end()) {
+    if (pool == nullptr) {
+      if (hipMalloc(reinterpret_cast<void**>(&pool), MAX_SLOTS * 8 * 128) != hipSuccess || hipMemset(pool, 0, MAX_SLOTS * 8 * 128) != hipSuccess) {
+        (void)hipGetLastError();
+        pool = nullptr;
+        return true;  // no counters: static order
+      }
+    }
+    if (used >= MAX_SLOTS) return true;
+    SchedSlot sl;
+    sl.dev = pool + used * 8 * 32;
+    ++used;
+    it = slots.emplace(st, sl).first;
+  }
+  SchedSlot& sl = it->second;
+  a.sched = sl.dev;
+  const int q8 = grid >> 3, r8 = grid & 7;
+  const int64_t full = ntiles / grid, rem = ntiles % grid;  // full >= 1: the launcher keeps grid <= ntiles
+  for (int x = 0; x < 8; ++x) {
+    a.sched_base[x] = sl.base[x];
+    const int cnt = q8 + (x < r8 ? 1 : 0);
+    const int off = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
+    int64_t last = rem - off;  // tiles of the partly filled last round that fall to this label
+    last = last < 0 ? 0 : (last > cnt ? cnt : last);
+    sl.base[x] += (uint32_t)(full * cnt + last);  // = first tiles (cnt) + drawn tiles ((full - 1) cnt + last): one draw per tile processed
+  }
+  return true;
+}
+
 template <int EPI, bool F8, bool CF8>
-int launch256e(const GemmArgs& a, hipStream_t st) {
+int launch256e(const GemmArgs& a_in, hipStream_t st) {
+  GemmArgs a = a_in;
   const int tiles_n = a.N / TN;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -605,6 +727,9 @@ int launch256e(const GemmArgs& a, hipStream_t st) {
   const int tiles_m = (int)((a.M + rows - 1) / rows);
   const int64_t ntiles = (int64_t)tiles_m * tiles_n;
   const int grid = (int)(ntiles < cus ? ntiles : cus);
+  const int nk = a.K / (F8 ? 128 : TK);
+  if (!F8 && nk >= 6 && a.no_dynamic == 0) sched_prepare(a, st, grid, ntiles);
+  else a.sched = nullptr;
   if constexpr (F8) {
     hipLaunchKernelGGL((gemm256e_kernel<EPI, 8, true, CF8>), dim3(grid), dim3(512), 0, st, a, tiles_m, tiles_n);
   } else {

@@ -22,6 +22,11 @@ struct GemmArgs {
   FastDiv div_tokens, div_frames;  // persistent kernel, QKV_EXPORT: row -> (frame, token), frame -> frame % T
   const float* col_scale;          // fp8 operands: per output column, activation scale x weight-row scale
   float out_inv_scale;             // fp8 output: stored value = e4m3(result * out_inv_scale)
+  // gemm256e.hip, dynamic tile hand-out (set by its launcher): eight monotonic counters, one 128-byte line per XCD label
+  // (blockIdx & 7), and the value each held when this launch was enqueued; NULL = tiles are dealt statically
+  uint32_t* sched;
+  uint32_t sched_base[8];
+  int no_dynamic;  // tests / A-B: 1 = keep the static order
 };
 
 // tuned bf16 kernels: 0 = launched, <0 = error, 1 = shape / epilogue not eligible

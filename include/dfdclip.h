@@ -163,8 +163,11 @@ int dfd_gemm_fp8(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
 int dfd_gemm_last_path(void);
 
 /* Tests and A/B measurements: 0 (default) = every kernel eligible; 1 = skip the ping-pong kernel, so that the round-2
- * persistent kernel serves the shapes both can (their results are bit-identical: tests/test_hip_kernels.py).  Per
- * thread; returns the previous value. */
+ * persistent kernel serves the shapes both can (their results are bit-identical: tests/test_hip_kernels.py); 3 = the
+ * ping-pong kernel hands out the tiles after a workgroup's first dynamically (per-XCD counters) instead of dealing them
+ * statically — for a chip shared with kernels of other streams that hold compute units unpredictably; measured 0.4 %
+ * slower than the static order when nothing of the kind happens, so not the default.  Per thread; returns the previous
+ * value. */
 int dfd_gemm_set_variant(int variant);
 
 /* C[Ma, Nb] (f32) = Aᵀ · B for tall row-major operands A [R, Ma], B [R, Nb] in `dtype` — the weight

@@ -357,6 +357,64 @@ def test_pingpong_gemm_ragged_panels_and_few_tiles(capi, M, N, K):
             assert torch.equal(c, want), (rep, opts)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(94560, 3072, 768, "gelu"), (50000, 2304, 768, "bias"), (94560, 768, 3072, "bias")])
+def test_pingpong_dynamic_tile_handout(capi, M, N, K, epi):
+    """Opt-in (variant 3): tiles after a workgroup's first are drawn from per-XCD counters (gemm256e.hip).  Which workgroup
+    computes a tile must not matter: the dynamic order and the static order (the default) give the same bits — alone;
+    with another stream's kernels holding compute units while the GEMM runs (the situation the hand-out exists for: late
+    workgroups take fewer tiles); with two streams launching GEMMs at once (each stream has counters of its own); and
+    launch after launch (the counters are never reset, each launch is told where they stand)."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    e = capi.EPI_BIAS_QUICKGELU if epi == "gelu" else capi.EPI_BIAS
+
+    def run(**kw):
+        c = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        capi.gemm(a, w, c, bias, e, stream_out=True, **kw)
+        return c
+
+    want = run()
+    assert capi.gemm_last_path() == 257
+    rows = torch.randint(0, M, (1024,), device="cuda", generator=g)
+    ref = a[rows].double() @ w.double().T + bias.double()
+    assert_close(want[rows], ref * torch.sigmoid(1.702 * ref) if epi == "gelu" else ref, 1e-4, 2 ** -8, "static order")
+    capi.gemm_set_variant(3)
+    try:
+        _dynamic_runs(run, want)
+    finally:
+        capi.gemm_set_variant(0)
+
+
+def _dynamic_runs(run, want):
+    if True:  # (kept as a block: the body is the hand-out exercised three ways)
+        for _ in range(5):
+            assert torch.equal(run(), want)
+        assert torch.equal(run(spare_cus=40), want)
+        # other work on the chip while the GEMM runs: a few hundred small kernels on a second stream
+        side = torch.cuda.Stream()
+        junk = torch.randn(64, 1 << 16, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(300):
+                junk = torch.sin(junk) * 1.0001
+        got = [run() for _ in range(4)]
+        torch.cuda.synchronize()
+        for c in got:
+            assert torch.equal(c, want)
+        # two streams launching GEMMs concurrently
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for _ in range(3):
+            for st in (s1, s2):
+                with torch.cuda.stream(st):
+                    outs.append(run())
+        torch.cuda.synchronize()
+        for c in outs:
+            assert torch.equal(c, want)
+
+
 @pytest.mark.parametrize("M,N,K", [(1024 + 96, 768, 256), (30 * 196 * 3 + 17, 768, 256), (9000, 768, 768), (5000, 1024, 384)])
 @pytest.mark.parametrize("in_place,p", [(False, 0.0), (True, 0.0), (False, 0.5)])
 def test_pingpong_residual_pos_equals_relaunching(capi, M, N, K, in_place, p):
