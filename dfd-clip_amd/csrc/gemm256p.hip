@@ -496,7 +496,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmArgs a, int til
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
             // row ii*16 + er, 8-byte unit (j*4 + eq) ^ ((row & 7) << 1)
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<unsigned char*>(reinterpret_cast<uintptr_t>(park + ii * 2048) ^ (uintptr_t)(j << 5))) = o;
+            // (XOR on the LDS byte address, cast back to an LDS pointer: through a generic pointer this became flat_store)
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+            *reinterpret_cast<lds_bf16x4*>(((uint32_t)(uintptr_t)(lds_ptr_t)(park + ii * 2048)) ^ (uint32_t)(j << 5)) = o;
           }
         }
 #pragma unroll
