@@ -34,30 +34,58 @@ from .weights import ARCHS, resolve_layer_indices
 CLIP_CACHE = os.path.expanduser("~/.cache/clip")  # where the reference's downloader leaves checkpoints (clip/clip.py:94)
 
 
-def auc_roc(weight=None, label_smoothing=0.0, *args, **kargs):
-    """Per-sample cross entropy (reference `src/models.py:34-45`)."""
-    def driver(logits, y, _weight=weight, _label_smoothing=label_smoothing):
-        if _weight:
-            _weight = torch.tensor(_weight, device=logits.device)
-        return torch.nn.functional.cross_entropy(logits, y, weight=_weight, label_smoothing=_label_smoothing,
-                                                 reduction="none")
-    return driver
+class TaskLoss:
+    """Unreduced loss of one task head: `loss(logits [B, out_dim], labels) -> [B]`.  The trainer takes the mean itself
+    (reference `src/trainer.py:154-155`); the config names a loss by the reference's factory name, optionally with
+    `args` (reference `src/models.py:447-452`)."""
+
+    def __call__(self, logits, labels):  # pragma: no cover
+        raise NotImplementedError
 
 
-def kl_div(*args, **kargs):
-    """Reference `src/models.py:28-31`."""
-    def driver(logits, y):
-        return torch.nn.functional.kl_div(torch.nn.functional.log_softmax(logits, dim=1), y, reduction="none")
-    return driver
+class PerSampleCrossEntropy(TaskLoss):
+    """`auc_roc` (reference `src/models.py:34-45`): cross entropy per sample, optional class weights and label smoothing."""
+
+    def __init__(self, weight=None, label_smoothing=0.0, **_unused):
+        self.weight = list(weight) if weight else None
+        self.label_smoothing = float(label_smoothing)
+
+    def __call__(self, logits, labels):
+        w = None if self.weight is None else torch.tensor(self.weight, device=logits.device)
+        return torch.nn.functional.cross_entropy(logits, labels, weight=w, label_smoothing=self.label_smoothing, reduction="none")
 
 
-def mse(logits, y):
-    """Reference `src/models.py:20-25` (140-bin expectation regression)."""
-    bins = torch.arange(140, dtype=torch.float32, device=logits.device)
-    return torch.pow(logits[:, :140].softmax(dim=-1) @ bins - y, 2) / 1000
+class PerElementKLDiv(TaskLoss):
+    """`kl_div` (reference `src/models.py:28-31`): KL(labels || softmax(logits)), element-wise."""
+
+    def __init__(self, **_unused):
+        pass
+
+    def __call__(self, logits, labels):
+        return torch.nn.functional.kl_div(logits.log_softmax(dim=1), labels, reduction="none")
 
 
-_LOSSES = {"auc_roc": auc_roc, "kl_div": kl_div, "mse": lambda *a, **k: mse}
+class ExpectationMSE(TaskLoss):
+    """`mse` (reference `src/models.py:20-25`): squared error of the expected bin index over the first 140 logits, / 1000."""
+    BINS = 140
+
+    def __init__(self, **_unused):
+        pass
+
+    def __call__(self, logits, labels):
+        bins = torch.arange(self.BINS, dtype=torch.float32, device=logits.device)
+        expected = logits[:, :self.BINS].softmax(dim=-1) @ bins
+        return (expected - labels) ** 2 / 1000
+
+
+TASK_LOSSES = {"auc_roc": PerSampleCrossEntropy, "kl_div": PerElementKLDiv, "mse": ExpectationMSE}
+
+
+def make_task_loss(spec):
+    """`spec`: a factory name, or a node {name, args} (the two forms the reference's configs use)."""
+    if isinstance(spec, str):
+        return TASK_LOSSES[spec]()
+    return TASK_LOSSES[spec.name](**(dict(spec.args) if "args" in spec else {}))
 
 
 def disable_gradients(module):
@@ -208,29 +236,10 @@ class Detector(RuntimeStateMixin, nn.Module):
         self.optimizer = config.optimizer
         self.train_mode = config.train_mode
         self.op_mode = config.op_mode
-        self.losses = []
-        for loss in config.losses:
-            if type(loss) == str:
-                self.losses.append(_LOSSES[loss]())
-            else:
-                self.losses.append(_LOSSES[loss.name](**(dict(loss.args) if "args" in loss else {})))
+        self.losses = [make_task_loss(spec) for spec in config.losses]
         self.layer_indices = resolve_layer_indices(config, len(self.encoder.transformer.resblocks))
         self.decoder = Decoder(self, config, num_frames)
-        if config.adapter.type == "none":
-            self.adapter = None
-        elif config.adapter.type == "normal":
-            self.adapter = CompInvAdapter(config, self, num_frames=num_frames)
-            logging.info("Adapter operates without pretrained weights!!!")
-        elif config.adapter.type == "pretrain":
-            self.adapter = CompInvAdapter(config, self, num_frames=num_frames)
-            data = torch.load(config.adapter.path, map_location="cpu", weights_only=True)
-            data = {".".join(k.split(".")[1:]): v for k, v in data.items() if "adapter" in k}
-            self.adapter.load_state_dict(data)
-            if config.adapter.frozen:
-                self.adapter = disable_gradients(self.adapter)
-            logging.info(f"Adapter operates with pretrained weights:{config.adapter.path}")
-        else:
-            raise NotImplementedError()
+        self.adapter = self._build_adapter(config, num_frames)
         self.transform = ClipTransform(self.encoder.input_resolution)
         # opt-in: replay the decoder's training-step kernels as HIP graphs (fixed batch shape; see decoder.py)
         self.static_graphs = False
@@ -502,6 +511,23 @@ class Detector(RuntimeStateMixin, nn.Module):
                 raise Exception("cannot return adaptive features without an adapter")
         return task_logits, features
 
+    def _build_adapter(self, config, num_frames):
+        """`adapter.type` none / normal (fresh) / pretrain (parameters from a checkpoint of a whole Detector, optionally
+        frozen): reference `src/models.py:454-478`.  Checkpoints are read with `weights_only=True`."""
+        kind = config.adapter.type
+        if kind == "none":
+            return None
+        if kind not in ("normal", "pretrain"):
+            raise NotImplementedError(f"adapter.type = {kind!r}")
+        adapter = CompInvAdapter(config, self, num_frames=num_frames)
+        if kind == "pretrain":
+            ckpt = torch.load(config.adapter.path, map_location="cpu", weights_only=True)
+            adapter.load_state_dict({k.split(".", 1)[1]: v for k, v in ckpt.items() if "adapter" in k})
+            if config.adapter.frozen:
+                adapter = disable_gradients(adapter)
+        logging.info("adapter %s: %s", config.adapter.struct.type, "fresh parameters" if kind == "normal" else f"parameters of {config.adapter.path}")
+        return adapter
+
     def forward(self, x, y, m, comp=None, speed=None, train=False, single_task=None, *args, **kargs):
         b, t, c, h, w = x.shape
         if "ema_frame" in self.op_mode and self.op_mode.ema_frame:
@@ -525,41 +551,50 @@ class Detector(RuntimeStateMixin, nn.Module):
         return task_losses, task_logits, self._other_losses(task_losses, video_features, features, comp, speed, b, x.device)
 
     def _other_losses(self, task_losses, video_features, features, comp, speed, b, device):
-        """Auxiliary training losses of the reference that are reachable there (temporal ranking / triplet,
-        models.py:680-736), on the [B, D] video features: plain torch arithmetic on small tensors,
-        differentiable through the HIP autograd nodes."""
-        other = {}
-        F_ = torch.nn.functional
-        if "temporal" in self.train_mode:
-            order = torch.argsort(speed, descending=True).tolist()
-            if self.train_mode.temporal == "ranking":  # faster clips must score higher (models.py:684-704)
-                z = (video_features @ self.ranking_transform_param).squeeze()
-                parts = []
-                for rk in range(b - 1):
-                    hi = z[order[rk]].repeat(b - 1 - rk)
-                    lo = z[order[rk + 1:], ...]
-                    parts.append(F_.margin_ranking_loss(hi, lo, torch.ones(b - 1 - rk, device=device), reduction="none"))
-                other["speed/rank"] = 0.05 * torch.cat(parts).mean()
-            elif self.train_mode.temporal == "triplet":  # models.py:706-733
-                rounds = min(comb(b, 3), 10)
-                ids = list(range(b))
-                random.shuffle(ids)
-                trip = iter(combinations(ids, 3))
-                loss = torch.tensor(0.0, device=device)
-                for _ in range(rounds):
-                    a_, p_, n_ = sorted(next(trip), key=lambda j: order.index(j))
-                    loss = loss + F_.triplet_margin_loss(anchor=video_features[a_], positive=video_features[p_],
-                                                         negative=video_features[n_], margin=torch.abs(speed[n_] - speed[p_]))
-                    loss = loss + F_.triplet_margin_loss(anchor=video_features[n_], positive=video_features[p_],
-                                                         negative=video_features[a_], margin=torch.abs(speed[p_] - speed[a_]))
-                other["speed/triplet"] = 0.01 * loss / (rounds * 2)
-            else:
-                raise NotImplementedError()
-        return other
+        """The reference's auxiliary training losses that can be reached there — the playback-speed terms on the [B, D]
+        video features (reference `src/models.py:680-736`).  Small tensors, plain torch arithmetic, differentiable
+        through the HIP autograd nodes."""
+        if "temporal" not in self.train_mode:
+            return {}
+        by_speed = torch.argsort(speed, descending=True).tolist()  # clip indices, fastest first
+        kind = self.train_mode.temporal
+        if kind == "ranking":
+            return {"speed/rank": 0.05 * self._speed_ranking(video_features, by_speed, device)}
+        if kind == "triplet":
+            return {"speed/triplet": 0.01 * self._speed_triplets(video_features, speed, by_speed, device)}
+        raise NotImplementedError(f"train_mode.temporal = {kind!r}")
+
+    def _speed_ranking(self, feats, by_speed, device):
+        """Every faster clip must out-score every slower one by the margin-ranking default (`:684-704`): mean over the
+        B (B - 1) / 2 ordered pairs."""
+        score = (feats @ self.ranking_transform_param).squeeze()
+        n = len(by_speed)
+        terms = [torch.nn.functional.margin_ranking_loss(score[by_speed[i]].repeat(n - 1 - i), score[by_speed[i + 1:], ...],
+                                                         torch.ones(n - 1 - i, device=device), reduction="none")
+                 for i in range(n - 1)]
+        return torch.cat(terms).mean()
+
+    def _speed_triplets(self, feats, speed, by_speed, device):
+        """Up to ten random clip triples, ordered by speed (fast, middle, slow); the middle clip must sit closer to each end
+        than the other end does, by the speed gap (`:706-733`).  Mean over both directions of every triple."""
+        n = len(by_speed)
+        clips = list(range(n))
+        random.shuffle(clips)
+        triples = combinations(clips, 3)
+        count = min(comb(n, 3), 10)
+        total = torch.tensor(0.0, device=device)
+        for _ in range(count):
+            fast, mid, slow = sorted(next(triples), key=by_speed.index)
+            for anchor, other in ((fast, slow), (slow, fast)):
+                total = total + torch.nn.functional.triplet_margin_loss(anchor=feats[anchor], positive=feats[mid], negative=feats[other],
+                                                                        margin=torch.abs(speed[other] - speed[mid]))
+        return total / (2 * count)
 
     def configure_optimizers(self, lr):
-        params = [p for p in self.parameters() if p.requires_grad]
-        if self.optimizer == "sgd":
-            return torch.optim.SGD(params=params, lr=lr, weight_decay=self.weight_decay, momentum=0.95)
-        elif self.optimizer == "adamw":
-            return torch.optim.AdamW(params=params, lr=lr, weight_decay=self.weight_decay)
+        """Optimizer over the trainable parameters only — decoder (+ adapter); the encoder is frozen (reference
+        `src/models.py:740-754`: SGD with momentum 0.95, or AdamW; both with the config's weight decay).  A
+        `torch.optim.Optimizer`, so `OneCycleLR` and the trainer's `param_groups[0]["lr"]` read work unchanged."""
+        trainable = [p for p in self.parameters() if p.requires_grad]
+        make = {"sgd": lambda: torch.optim.SGD(trainable, lr=lr, momentum=0.95, weight_decay=self.weight_decay),
+                "adamw": lambda: torch.optim.AdamW(trainable, lr=lr, weight_decay=self.weight_decay)}.get(self.optimizer)
+        return make() if make is not None else None  # (an unknown name yields None in the reference too)

@@ -87,10 +87,12 @@ def allreduce_gradients(params):
         torch._foreach_copy_(list(views), grads)
     if flat.is_cuda and dist.get_backend() == "gloo" and _STAGE_GLOO:
         # gloo has no device path: ProcessGroupGloo stages a CUDA tensor through a pinned host buffer it allocates
-        # per call.  Entered while the device still has work queued, that allocation cannot reuse the previous
-        # step's block (its copy event is still pending), so every step pins and unpins another 156 MB — the
-        # multi-second "stall" of round 1's one-GPU rehearsal (tools/lab/dbg_pipe.py).  Stage through ONE
-        # persistent pinned buffer instead; RCCL ("nccl") reduces device buffers directly and never comes here.
+        # per call.  HYPOTHESIS for the multi-second steps of round 1's one-GPU rehearsal (never reproduced since:
+        # DESIGN.md §6): entered while the device still has work queued, that allocation cannot reuse the previous
+        # step's block (its copy event is still pending), so every step pins and unpins another 156 MB.  Not measured;
+        # what IS known is that those steps were host-bound (host CPU time == wall time).  Staging through ONE
+        # persistent pinned buffer removes the per-call allocation either way; RCCL ("nccl") reduces device buffers
+        # directly and never comes here.
         host = _pinned_like(flat)
         host.copy_(flat, non_blocking=True)
         torch.cuda.current_stream().synchronize()
