@@ -13,13 +13,25 @@ from tests.cases import build_case, load_golden, oracle_kwargs
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-3
-BF16_TOL = 5e-2
-# GELU-then-LayerNorm adapters on the tiny model normalise 32 post-GELU values per row: the LayerNorm
-# divides by their (small) spread, which amplifies the bf16 rounding of the K/V operands about 4x more than
-# the LayerNorm-first structs (measured 5.5e-2 with the projection kept in f32, fp32 path 1e-5)
-BF16_TOL_CASE = {"tiny_adapter_gl": 1e-1, "tiny_adapter_legacy": 1e-1}
-# ... and the same structs at the real width (ViT-B/16 keys, 768 -> 256 -> 768: the LayerNorm normalises 256 values per row)
-# stay inside the general bar: `vitb16_adapter_gl` / `_legacy` below
+BF16_TOL = 5e-2   # the documented ceiling for the bf16 path (1 % of the logits' norm) ...
+# ... and what each case actually measured on MI355X against the reference's fp32 logits (round 3,
+# profiles/r03_bf16_parity_measured.txt; the kernels are deterministic, so these repeat exactly): a case's bar is TWICE
+# its measured value (at least 5e-3), so a regression of the bf16 arithmetic shows long before the ceiling.
+BF16_MEASURED = {"tiny": 7.3e-3, "tiny_stride": 7.7e-4, "tiny_nopos": 2.5e-2, "tiny_augq": 1.7e-2, "small": 4.2e-3, "small14": 9.3e-4,
+                 "tiny_adapter_nln": 9.1e-3, "tiny_adapter_ln": 1.4e-2, "tiny_adapter_gl": 5.5e-2, "tiny_adapter_legacy": 5.5e-2,
+                 "tiny_global": 2.2e-3, "tiny_attnmode": 7.9e-3, "vitb16_adapter_gl": 2.4e-2, "vitb16_adapter_legacy": 2.4e-2,
+                 "vitb16_cfg1": 1.5e-2, "vitl14": 1.1e-2}
+# GELU-then-LayerNorm adapters on the tiny model normalise 32 post-GELU values per row: the LayerNorm divides by their
+# (small) spread, which amplifies the bf16 rounding of the K/V operands about 4x more than the LayerNorm-first structs
+# (5.5e-2; fp32 path 1e-5).  At the real width (768 -> 256 -> 768, `vitb16_adapter_gl` / `_legacy`) the same structs
+# measure 2.4e-2 — and 2.8e-3 from the reference's OWN bf16 run — so the exception is the 32-wide toy's, not the struct's.
+BF16_TOL_CASE = {"tiny_adapter_gl": 1.1e-1, "tiny_adapter_legacy": 1.1e-1}
+
+
+def bf16_bar(name):
+    return BF16_TOL_CASE.get(name, min(BF16_TOL, max(2 * BF16_MEASURED[name], 5e-3)))
+
+
 SUPPORTED = ["tiny", "tiny_stride", "tiny_nopos", "tiny_augq", "small", "small14", "tiny_adapter_nln", "tiny_adapter_ln", "tiny_adapter_gl", "tiny_adapter_legacy",
              "tiny_global", "tiny_attnmode", "vitb16_adapter_gl", "vitb16_adapter_legacy"]
 
@@ -41,13 +53,14 @@ def test_detector_logits_match_reference(name, precision):
     with torch.no_grad():  # the reference's evaluator and inference loops run under no_grad (evaluator.py:50)
         losses, logits = det(x, [y], m, single_task=0)
         plog, feats = det.predict(x, m, with_video_features=True)
-    tol = FP32_TOL if precision == "fp32" else BF16_TOL_CASE.get(name, BF16_TOL)
+    tol = FP32_TOL if precision == "fp32" else bf16_bar(name)
     err = np.abs(logits[0].cpu().numpy() - g["logits"]).max()
     print(f"{name}/{precision}: max |dlogit| = {err:.3e}")
     assert err <= tol
     assert torch.equal(plog[0], logits[0])
-    np.testing.assert_allclose(feats["video"].cpu().numpy(), g["video_feature"], atol=tol * 2, rtol=0)
-    np.testing.assert_allclose(losses[0].cpu().numpy(), g["losses"], atol=tol * 2, rtol=0)
+    ftol = FP32_TOL if precision == "fp32" else BF16_TOL_CASE.get(name, BF16_TOL)  # (features / losses: the documented ceiling)
+    np.testing.assert_allclose(feats["video"].cpu().numpy(), g["video_feature"], atol=ftol * 2, rtol=0)
+    np.testing.assert_allclose(losses[0].cpu().numpy(), g["losses"], atol=ftol * 2, rtol=0)
     np.testing.assert_allclose(logits[0].norm(dim=-1).cpu().numpy(), 5.0, atol=1e-4)
 
 
@@ -120,7 +133,7 @@ def test_vitb16_cfg1_matches_reference(precision):
         losses, logits = det(x, [y], m, single_task=0)
     err = np.abs(logits[0].cpu().numpy() - g["logits"]).max()
     print(f"vitb16_cfg1/{precision}: max |dlogit| = {err:.3e}")
-    assert err <= (FP32_TOL if precision == "fp32" else BF16_TOL)
+    assert err <= (FP32_TOL if precision == "fp32" else bf16_bar("vitb16_cfg1"))
     rows = list(g["slice_rows"])
     enc = det.encoder(case["x"].flatten(0, 1)[[0, 15]].cuda())
     tol = 5e-4 if precision == "fp32" else 1e-1
@@ -146,10 +159,11 @@ def test_vitl14_matches_reference(precision):
         _, feats = det.predict(x, m, with_video_features=True)
     err = np.abs(logits[0].cpu().numpy() - g["logits"]).max()
     print(f"vitl14/{precision}: max |dlogit| = {err:.3e}")
-    tol = FP32_TOL if precision == "fp32" else BF16_TOL
+    tol = FP32_TOL if precision == "fp32" else bf16_bar("vitl14")
     assert err <= tol
-    np.testing.assert_allclose(feats["video"].cpu().numpy(), g["video_feature"], atol=2 * tol, rtol=0)
-    np.testing.assert_allclose(losses[0].cpu().numpy(), g["losses"], atol=2 * tol, rtol=0)
+    ftol = FP32_TOL if precision == "fp32" else BF16_TOL
+    np.testing.assert_allclose(feats["video"].cpu().numpy(), g["video_feature"], atol=2 * ftol, rtol=0)
+    np.testing.assert_allclose(losses[0].cpu().numpy(), g["losses"], atol=2 * ftol, rtol=0)
     rows = list(g["slice_rows"])
     enc = det.encoder(case["x"].flatten(0, 1)[[0, 3]].cuda())
     tol_kv = 5e-4 if precision == "fp32" else 1e-1
