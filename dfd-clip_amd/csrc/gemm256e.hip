@@ -26,13 +26,15 @@
 //   * a store whose lanes are ALL out of range is dropped by the buffer unit and retires at once, ahead of older loads:
 //     a wait that counts such stores waits for nothing.  A wave therefore counts its previous epilogue's stores only
 //     when every one of them was a real store (all of its rows inside M); otherwise it waits as if there were none.
-// Tiles after a workgroup's first are handed out dynamically WITHIN an XCD: the workgroups that share an XCD label
-// (blockIdx & 7) draw the label's tile list — the same XCD-contiguous runs the static order gave them — from one counter.
-// A workgroup that starts late or runs slowly because another stream's kernels hold its CU (the decoder's kernels beside a
-// pipelined encoder pass, an RCCL all-reduce) then simply takes fewer tiles, instead of making the whole launch wait for
-// its full share.  One returning atomic per tile, issued by wave 0 at the top of a tile for the tile after it and counted
-// in that wave's waits; the counters are monotonic (the launcher passes the value each will have when the launch
-// starts), so nothing has to be reset.  Launches that are being captured into a HIP graph keep the static order.
+// OPT-IN (dfd_gemm_set_variant(3); off by default): tiles after a workgroup's first handed out dynamically WITHIN an XCD —
+// the workgroups that share an XCD label (blockIdx & 7) draw the label's tile list (the same XCD-contiguous runs the
+// static order gives them) from one counter, so that a workgroup that starts late or runs slowly because another
+// stream's kernels hold its CU (an RCCL all-reduce, say) takes fewer tiles instead of making the launch wait for its full
+// share.  One returning atomic per tile, issued by wave 0 (EXEC narrowed to one lane: an out-of-range lane offset makes an
+// atomic FAULT, it is not dropped like a store) at the top of a tile for the tile after it, counted in that wave's waits
+// and published through LDS with explicit DS instructions; the counters are monotonic (the launcher passes the value
+// each will have when the launch starts), so nothing is reset.  Captured launches keep the static order.  Measured on an
+// undisturbed chip: 0.4 % slower than the static order (profiles/r03_gemm_dynamic_vs_static_ab.txt), bit-identical.
 //
 // Measured on MI355X against gemm256p (same process, interleaved; profiles/r03_gemm_pingpong_lab.txt): c_fc 0.411 ->
 // 0.398-0.403 ms, q|k|v 0.285-0.292 -> 0.272-0.279, c_proj 0.388-0.395 -> 0.343-0.349, 8192^3 1,434 -> 1,590 TFLOP/s;
