@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512) void gemm256e_kernel(const GemmArgs a, int til
         constexpr bool stores_young = HEAD < 2 && 4 * HEAD + p <= DEPTH - 2;
         constexpr bool bias_young = END <= 1 && 4 * (1 - END) + p <= DEPTH - 2;
         if constexpr (stores_young) {  // (never together with the bias window: nk >= 6)
-          if (first_tile) wait_vm<NB>();
+          if (first_tile || (VAR & 24) != 0) wait_vm<NB>();  // (ablations 8 / 16 issue no stores)
           else wait_vm<NB + STORES>();
         } else {
           wait_vm<NB + (bias_young ? 4 : 0)>();
@@ -252,6 +252,13 @@ __global__ __launch_bounds__(512) void gemm256e_kernel(const GemmArgs a, int til
     ktile(nk - 2, C0{}, C2{}, C1{});
     ktile(nk - 1, C1{}, C2{}, C0{});
 
+    if constexpr ((VAR & 16) != 0) {  // ablation: no epilogue at all (the accumulators are only kept alive)
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+      asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));
+    } else {
     // ---- epilogue (as gemm256p.hip: bias, activation, LDS-staged whole-line stores left in flight) ----------------
     int le = lane;
     asm volatile("" : "+v"(le));
@@ -303,8 +310,10 @@ __global__ __launch_bounds__(512) void gemm256e_kernel(const GemmArgs a, int til
         const v4i d = *reinterpret_cast<const v4i*>(dsrc + rr * 1024);
         const int rloc = q * 32 + rr * 8;
         uint32_t off = rloc < rows_left ? cbase + (uint32_t)rloc * (uint32_t)(a.ldc * 2) : 0xffffffffu;
-        store_out(d, srdC, off, a.stream_out);
+        if constexpr ((VAR & 8) == 0) store_out(d, srdC, off, a.stream_out);  // ablation 8: everything but the stores
+        else asm volatile("" ::"v"(d), "v"(off));
       }
+    }
     }
     if (!has_next) break;
     first_tile = false;
@@ -354,7 +363,7 @@ int dfd_gemm256e_launch(const GemmArgs& a, int epi, int depth, hipStream_t st) {
     if (epi == DFD_EPI_BIAS_QUICKGELU) return launch256e<DFD_EPI_BIAS_QUICKGELU, D, V>(a, st); \
     return 1;                                                                               \
   }
-  E_CASE(4, 0) E_CASE(5, 0) E_CASE(6, 0) E_CASE(6, 1) E_CASE(6, 2) E_CASE(6, 4) E_CASE(4, 1) E_CASE(4, 2) E_CASE(4, 4) E_CASE(4, 3)
+  E_CASE(4, 0) E_CASE(5, 0) E_CASE(6, 0) E_CASE(6, 4) E_CASE(6, 8) E_CASE(6, 16)
 #undef E_CASE
   return 1;
 }
