@@ -93,6 +93,7 @@ def parse():
     ap.add_argument("--spare-gemms", default=None, help="lab: comma list of the block's GEMMs (qkv,out,fc,proj) that leave the spare CUs free")
     ap.add_argument("--gemm-stream-out", default=None,
                     help="comma list of encoder GEMM outputs stored non-temporally (qkv,out,fc,proj; 'none'); default = package default")
+    ap.add_argument("--no-spare-in-eval", action="store_true", help="A/B: in forward-only mode no GEMM leaves spare CUs to the decoder stream (round 2's behaviour)")
     ap.add_argument("--gemm-dynamic", action="store_true",
                     help="A/B: the persistent GEMM hands out the tiles after a workgroup's first from per-XCD counters instead of dealing them statically")
     ap.add_argument("--adapter", default="none", choices=["none", "nln", "z0", "ln"],
@@ -129,6 +130,7 @@ def build_model(args, device):
         det.pipeline_spare_cus = args.spare_cus
     if args.spare_layers >= 0:
         det.pipeline_spare_layers = args.spare_layers
+    det.pipeline_spare_in_eval = not args.no_spare_in_eval
     if args.spare_gemms is not None:
         on = set(args.spare_gemms.split(",")) - {"none", ""}
         det.encoder.spare_gemms = {k: k in on for k in det.encoder.spare_gemms}
