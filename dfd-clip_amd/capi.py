@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdfdclip_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_PATCH_EMBED, EPI_QKV_EXPORT, EPI_RESIDUAL_POS = range(6)
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _DTYPE = {torch.float32: F32, torch.bfloat16: BF16}
 FP8 = 2           # ABI code of OCP e4m3; stored in uint8 / torch.float8_e4m3fn tensors
@@ -102,6 +102,8 @@ SIGNATURES = {
                                           c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dfd_linear_rows_bwd_weight": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dfd_transpose_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dfd_sgd_blocks": (c_int64, [c_int64, c_int, c_int, c_int]),
+    "dfd_sgd_step": (c_int, [c_void_p, c_int, c_int64, c_float, c_float, c_float, c_int, c_void_p]),
     "dfd_layernorm_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_float, c_int, c_void_p]),
     "dfd_quickgelu": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(DropoutDesc), c_void_p]),
@@ -524,6 +526,18 @@ def transpose(src, dst):
     R, C = src.shape
     _check(load_library().dfd_transpose_f32(_ptr(src), _ptr(dst), R, C, _stream()), "dfd_transpose_f32")
     return dst
+
+
+def sgd_blocks(numel, rows=0, cols=0, mirrored=False):
+    return int(load_library().dfd_sgd_blocks(int(numel), int(rows), int(cols), 1 if mirrored else 0))
+
+
+def sgd_step(table, n, total_blocks, lr, momentum, weight_decay, first_step):
+    """`table`: device int64 tensor [n, 7] laid out as dfd_sgd_param (p, g, buf, mirror, numel, rows | cols << 32, first_block)."""
+    _dev(table)
+    assert table.dtype == torch.int64 and table.is_contiguous() and table.shape == (n, 7)
+    _check(load_library().dfd_sgd_step(_ptr(table), int(n), int(total_blocks), float(lr), float(momentum), float(weight_decay),
+                                       1 if first_step else 0, _stream()), "dfd_sgd_step")
 
 
 def layernorm_bwd(x, gamma, dy, dx, dgamma, dbeta, xhat_ws, accumulate_dx=False, eps=1e-5):

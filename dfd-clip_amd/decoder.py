@@ -58,7 +58,7 @@ class DecoderTransformer(_Holder):
 
 
 class Decoder(RuntimeStateMixin, nn.Module):
-    _RUNTIME_STATE = {"_wt_cache": {}, "_after_backward": None, "_param_list": None, "_graphs_failed": None}
+    _RUNTIME_STATE = {"_wt_cache": {}, "_after_backward": None, "_param_list": None, "_graphs_failed": None, "_mirror_ids": None}
 
     def invalidate_caches(self):
         """After parameters were rewritten in place behind autograd's back."""
@@ -100,6 +100,7 @@ class Decoder(RuntimeStateMixin, nn.Module):
                 setattr(self, name, nn.Parameter(scale * torch.randn(width, od)))
             self.task_projections.append([getattr(self, name) for name in names])
         self._wt_cache = {}  # name -> (parameter version, transposed f32 copy) for the row-streaming linear kernel
+        self._mirror_ids = None
         self._param_list = None
         # Opt-in (Detector.static_graphs): the ~450 small launches of one training step of the decoder are
         # captured into two HIP graphs (forward kernels, backward kernels) per input signature and replayed,
@@ -172,16 +173,56 @@ class Decoder(RuntimeStateMixin, nn.Module):
 
     def _wt(self, name, w):
         """Transposed [K, N] copy of Linear weight `name`, refreshed when the parameter changed (its
-        autograd version counter moves on optimizer.step / load_state_dict / .to())."""
+        autograd version counter moves on optimizer.step / load_state_dict / .to()).  The copy keeps its ADDRESS across
+        refreshes (captured graphs read it), and `FusedSGD` rewrites it inside its own launch (`mirrors_written`)."""
         p = w[name]
         key = (p._version, p.data_ptr(), p.device)
         hit = self._wt_cache.get(name)
         if hit is None or hit[0] != key:
             src = p.to(torch.float32).contiguous()
-            dst = torch.empty(src.shape[1], src.shape[0], device=src.device, dtype=torch.float32)
+            dst = hit[1] if (hit is not None and hit[1].shape == (src.shape[1], src.shape[0]) and hit[1].device == src.device) else \
+                torch.empty(src.shape[1], src.shape[0], device=src.device, dtype=torch.float32)
             capi.transpose(src, dst)
             self._wt_cache[name] = hit = (key, dst)
         return hit[1]
+
+    # ---- transposed copies kept by the optimizer (optim.FusedSGD) -------------------------------------------------
+    _MIRRORED = ("attn.in_proj.weight", "attn.out_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight")
+
+    def _mirror_names(self):
+        if self._mirror_ids is None:  # the module tree is static
+            self._mirror_ids = {id(p): n for n, p in self.named_parameters() if n.endswith(self._MIRRORED) and p.dim() == 2}
+        return self._mirror_ids
+
+    def current_mirror(self, p):
+        """The transposed copy `_wt` would hand out for `p` right now (no refresh), or None."""
+        hit = self._wt_cache.get(self._mirror_names().get(id(p)))
+        return None if hit is None else hit[1]
+
+    def mirror_for(self, p):
+        """The transposed copy of Linear weight `p` that `_wt` hands to the kernels, created (and filled) on demand; None for
+        parameters the forward does not read transposed."""
+        name = self._mirror_names().get(id(p))
+        if name is None or not p.is_cuda:
+            return None
+        return self._wt(name, {name: p.detach()})
+
+    def mirrors_written(self, params):
+        """`FusedSGD` has just rewritten these parameters AND their transposed copies: the copies are current."""
+        names = self._mirror_names()
+        for p, mirror in params:
+            n = names.get(id(p))
+            hit = self._wt_cache.get(n)
+            if hit is not None and hit[1] is mirror:  # (a copy replaced since the optimizer planned is refreshed by `_wt` instead)
+                self._wt_cache[n] = ((p._version, p.data_ptr(), p.device), hit[1])
+
+    def _refresh_mirrors(self, w):
+        """Before a captured forward is replayed: the graph reads the transposed copies at fixed addresses and contains no
+        transpose, so whatever changed the weights without maintaining them (another optimizer, a checkpoint load) is caught
+        up with here, eagerly."""
+        for n in w:
+            if n.endswith(self._MIRRORED) and w[n].dim() == 2:
+                self._wt(n, w)
 
     def _lin_ws(self, B, dev):
         D = self.width
@@ -501,7 +542,9 @@ class Decoder(RuntimeStateMixin, nn.Module):
             # refreshed before every replay, so each step draws new masks and its backward regenerates them
             ent = dict(mask=mask.clone(), bwd={}, rng=None if drop_rng is None else drop_rng.clone())
             self._forward_kernels(w, k_all, v_all, ent["mask"], B, T, P, save=True, drop_rng=ent["rng"], kv_pos=kv_pos)  # eager once: lazy initialisations
-            self._wt_cache.clear()  # the weight transposes must be nodes of the graph (weights change every step)
+            # the transposed weight copies are NOT nodes of the graph: they sit at fixed addresses, `FusedSGD` rewrites them
+            # with the weights, and `_refresh_mirrors` (below, before every replay) catches up after anything else
+            self._refresh_mirrors(w)
             torch.cuda.synchronize()
             try:
                 # thread_local: other threads of the process (the RCCL watchdog, a data loader) may keep calling into
@@ -519,6 +562,7 @@ class Decoder(RuntimeStateMixin, nn.Module):
         ent["mask"].copy_(mask)
         if drop_rng is not None:
             ent["rng"].copy_(drop_rng)
+        self._refresh_mirrors(w)
         ent["fwd"].replay()
         return ent
 

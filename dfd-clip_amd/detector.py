@@ -598,6 +598,10 @@ class Detector(RuntimeStateMixin, nn.Module):
         `src/models.py:740-754`: SGD with momentum 0.95, or AdamW; both with the config's weight decay).  A
         `torch.optim.Optimizer`, so `OneCycleLR` and the trainer's `param_groups[0]["lr"]` read work unchanged."""
         trainable = [p for p in self.parameters() if p.requires_grad]
+        if self.optimizer == "sgd" and trainable and all(p.is_cuda and p.dtype == torch.float32 for p in trainable):
+            # one HIP launch per step, which also keeps the decoder's transposed weight copies current (optim.py)
+            from .optim import FusedSGD
+            return FusedSGD(trainable, lr=lr, momentum=0.95, weight_decay=self.weight_decay, mirrors=self.decoder)
         make = {"sgd": lambda: torch.optim.SGD(trainable, lr=lr, momentum=0.95, weight_decay=self.weight_decay),
                 "adamw": lambda: torch.optim.AdamW(trainable, lr=lr, weight_decay=self.weight_decay)}.get(self.optimizer)
         return make() if make is not None else None  # (an unknown name yields None in the reference too)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DFD_ABI_VERSION 14
+#define DFD_ABI_VERSION 15
 
 enum { DFD_F32 = 0, DFD_BF16 = 1, DFD_FP8 = 2 /* OCP e4m3 ("e4m3fn"), one byte per element */ };
 
@@ -298,6 +298,26 @@ int dfd_linear_rows_bwd_weight(const float* dy, int64_t lddy, const float* x, in
 
 /* dst[cols, rows] = src[rows, cols]ᵀ — the data gradient of dfd_linear_rows is dfd_linear_rows on Wᵀ. */
 int dfd_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream);
+
+/* One fused step of SGD with momentum and weight decay over a list of f32 parameters — `Detector.configure_optimizers`
+ * (reference src/models.py:740-754, stepped once per batch by src/trainer.py:157-177) — in torch.optim.SGD's arithmetic:
+ * g = grad + wd p; buf = first_step ? g : momentum buf + g; p -= lr buf.  An entry with `mirror` != NULL is a [rows, cols]
+ * weight whose transposed copy [cols, rows] (what dfd_linear_rows_t reads) is rewritten by the same launch.  The table
+ * lives in DEVICE memory (the pointers of a model do not change from step to step; lr and momentum do, every step, under
+ * OneCycleLR); `first_block` of entry i = sum of dfd_sgd_blocks(...) of the entries before it, `total_blocks` the sum over
+ * all. */
+typedef struct dfd_sgd_param {
+  float* p;
+  const float* g;
+  float* buf;
+  float* mirror;
+  int64_t numel;
+  int32_t rows, cols;
+  int64_t first_block;
+} dfd_sgd_param;
+int64_t dfd_sgd_blocks(int64_t numel, int rows, int cols, int mirrored);
+int dfd_sgd_step(const dfd_sgd_param* table_dev, int n, int64_t total_blocks, float lr, float momentum, float weight_decay,
+                 int first_step, void* stream);
 
 /* LayerNorm backward over `rows` rows: dx = [dx +] ∂L/∂x (accumulate_dx != 0 adds into dx: the
  * residual branch), dgamma/dbeta [cols] summed over rows; xhat_ws: rows*cols floats of scratch. */
