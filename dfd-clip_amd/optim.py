@@ -95,10 +95,12 @@ class FusedSGD(torch.optim.Optimizer):
                 if tab is None:
                     tab = plan["tables"][tkey] = self._table(part, active[0].device)
                 capi.sgd_step(tab[0], len(part), tab[1], group["lr"], group["momentum"], group["weight_decay"], first)
+            # the kernel wrote through raw pointers: caches keyed on a parameter's version counter must see the update
+            # (the call takes an ITERABLE of tensors; handed one tensor it would iterate over its rows)
+            torch._C._increment_version([e["p"] for e in plan["entries"]])
             written = []
             for e in plan["entries"]:
                 e["fresh"] = False
-                torch._C._increment_version(e["p"])  # the kernel wrote through raw pointers: caches keyed on the version must see it
                 if e["mirror"] is not None:
                     written.append((e["p"], e["mirror"]))
             if written:
