@@ -22,7 +22,7 @@ FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-
 # build asks the compiler for its resource report on these files and refuses a kernel with scratch.
 # (gemm256p.hip's fp8 forms reload two registers from scratch in their epilogue; its K loop waits for vmcnt(0) every
 # step, so that only over-waits there.  gemm256e.hip's loop never waits for zero.)
-NO_SCRATCH = {"gemm256e.hip": "gemm256e_kernel"}
+NO_SCRATCH = {"gemm256e.hip": "gemm256e_kernel", "attention_mfma_xrow.hip": "attn_mfma_xrow_kernel"}
 
 
 def _hipcc():

@@ -15,18 +15,9 @@
 //     second product Oᵀ = Vᵀ·Pᵀ (accumulator-as-operand, k order permuted the same way on the
 //     Vt fragment), so P never touches LDS; a lane ends with 4 consecutive output channels of
 //     its query per register group and stores them as 8-byte pieces.
-#include "common.hpp"
+#include "attention_common.hpp"
 
 namespace {
-
-constexpr int HD = 64;
-
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
 
 template <int NB> struct Lds {
   static constexpr int KEYS = NB * 32;
@@ -231,32 +222,6 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const bf16_t* __restr
 // c ^ ((r >> 1) & 7).
 // Items are dealt so that the workgroups of one XCD (blockIdx % 8) walk the heads of the same few frames at the
 // same time: their 128-byte pieces of a qkv row are neighbours in memory.
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef short short4v __attribute__((ext_vector_type(4)));
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-
-// LDS-DMA by the loader wave, in 1 KB pieces (8 rows): lane (sub = lane >> 3, pos = lane & 7) moves 16-byte chunk
-// pos^swizzle of row 8*piece + sub; the swizzle of the K and Q images, ((row >> 1) & 7), depends on the piece only
-// through its parity.  attn_stage_k / _v issue exactly `np` instructions (every piece has live lanes), _q 4*NB.
-__device__ __forceinline__ void attn_stage_k(__amdgpu_buffer_rsrc_t srd, unsigned char* kimg, uint32_t sbase, uint32_t ldq,
-                                             uint32_t Db, int lane, int np, int tokens) {
-  const int sub = lane >> 3, pos = lane & 7;
-  const uint32_t row0 = (uint32_t)sub * ldq;
-  const uint32_t k_even = row0 + Db + ((pos ^ ((sub >> 1) & 3)) << 4), k_odd = row0 + Db + ((pos ^ (((sub >> 1) & 3) | 4)) << 4);
-  for (int p = 0; p < np; ++p) {
-    if (8 * p + sub < tokens)  // lanes past the image write nothing
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(kimg + p * 1024), 16, ((p & 1) ? k_odd : k_even) + p * 8 * ldq, sbase, 0, 0);
-  }
-}
-__device__ __forceinline__ void attn_stage_v(__amdgpu_buffer_rsrc_t srd, unsigned char* vimg, uint32_t sbase, uint32_t ldq,
-                                             uint32_t Db, int lane, int np, int tokens) {
-  const int sub = lane >> 3, pos = lane & 7;
-  const uint32_t v_any = (uint32_t)sub * ldq + 2 * Db + ((pos ^ (((sub >> 1) & 1) << 2)) << 4);
-  for (int p = 0; p < np; ++p) {
-    if (8 * p + sub < tokens)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(vimg + p * 1024), 16, v_any + p * 8 * ldq, sbase, 0, 0);
-  }
-}
 template <int NB>
 __device__ __forceinline__ void attn_stage_q(__amdgpu_buffer_rsrc_t srd, unsigned char* qimg, uint32_t sbase, uint32_t ldq, int lane,
                                              int tokens) {
@@ -333,7 +298,10 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {
   }
 }
 
-template <int NB>
+// SHORT: the last key block holds at most 8 keys (197 = 6*32 + 5, 257 = 8*32 + 1), i.e. only elements 0..3 of its score
+// registers can be live — the other twelve are neither exponentiated nor multiplied (a tenth of the softmax, which bounds the
+// kernel, and one of the 2*NB steps of the second product).
+template <int NB, bool SHORT>
 __global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __restrict__ qkv, uint32_t ldq /* bytes */,
                                                                 bf16_t* __restrict__ out, uint32_t ldo /* bytes */,
                                                                 int tokens, int heads, int n_frames, uint32_t qkv_bytes,
@@ -467,81 +435,10 @@ __global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __
     __builtin_amdgcn_sched_barrier(0);
     barrier();  // every wave has read its K fragments (the loader may overwrite the K image); V is in
 
-    // ---- softmax over the key axis ------------------------------------------------------------------
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int key = (NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (key >= tokens) S[NB - 1][e] = -INFINITY;
-    }
-    // The softmax is the VALU-bound part of the kernel (two waves per SIMD): v_max3 without the NaN
-    // canonicalisation fmaxf() drags in, packed f32 multiply-add and packed row sums.
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb)
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) mx = vmax3(mx, S[kb][e], S[kb][e + 1]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sl2 = scale_log2e;
-    float nmc = -mx * scale_log2e;
-    asm volatile("" : "+s"(sl2));  // opaque scalars: the vector expression below packs into v_pk_fma_f32
-    f32x16 lv;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) lv[e] = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) {
-        const f32x2v t = __builtin_elementwise_fma(f32x2v{S[kb][e], S[kb][e + 1]}, f32x2v{sl2, sl2}, f32x2v{nmc, nmc});
-        S[kb][e] = __builtin_amdgcn_exp2f(t[0]);
-        S[kb][e + 1] = __builtin_amdgcn_exp2f(t[1]);
-      }
-      lv += S[kb];
-    }
-    float l = ((lv[0] + lv[1]) + (lv[2] + lv[3])) + ((lv[4] + lv[5]) + (lv[6] + lv[7])) +
-              (((lv[8] + lv[9]) + (lv[10] + lv[11])) + ((lv[12] + lv[13]) + (lv[14] + lv[15])));
-    l += __shfl_xor(l, 32, 64);
-
-    // ---- Oᵀ[d][q] = Σ_key V[key][d] · Pᵀ[key][q]: V operand through the transposing read ------------
-    // lane (r, h): d row r of tile dt, keys base + 4h + {0..3} and base + 8 + 4h + {0..3}.  In its 16-lane
-    // group (d columns 16*(r>>4) ..), lane 4q+p supplies the address of key row q, d columns 4p..4p+3.
+    // ---- softmax over the key axis, then Oᵀ[d][q] = Σ_key V[key][d] · Pᵀ[key][q] (attention_common.hpp) -------------
+    const float l = attn_softmax<NB, SHORT>(S, tokens, h, scale_log2e);
     f32x16 O[2];
-    const int tq = (lane & 15) >> 2, tp = lane & 3, rr = (lane >> 4) & 1;
-    auto read_v = [&](bf16x8 (&vf)[2], int step) {
-      const int kbase = (step >> 1) * 32 + 16 * (step & 1) + 4 * h + tq;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const int c = 4 * dt + 2 * rr + (tp >> 1);
-        const int k1 = kbase, k2 = kbase + 8;
-        const unsigned char* a1 = Vs + k1 * 128 + ((c ^ (((k1 >> 1) & 1) << 2)) << 4) + 8 * (tp & 1);
-        const unsigned char* a2 = Vs + k2 * 128 + ((c ^ (((k2 >> 1) & 1) << 2)) << 4) + 8 * (tp & 1);
-        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)a1);
-        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)a2);
-        short8 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-        vf[dt] = __builtin_bit_cast(bf16x8, v);
-      }
-    };
-    auto mma_v = [&](const bf16x8 (&vf)[2], int step) {
-      const int kb = step >> 1, sl = step & 1;
-      bf16x8 pf;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)S[kb][8 * sl + j];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pf, step == 0 ? zero16 : O[dt], 0, 0, 0);
-    };
-    bf16x8 vfa[2], vfb[2];
-    read_v(vfa, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int step = 0; step < 2 * NB; step += 2) {
-      read_v(vfb, step + 1);
-      mma_v(vfa, step);
-      __builtin_amdgcn_sched_barrier(0);
-      if (step + 2 < 2 * NB) read_v(vfa, step + 2);
-      mma_v(vfb, step + 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    attn_pv<NB, SHORT>(S, Vs, lane, O);
     // ---- output: [q][64] bf16 through my (consumed) Q image, then whole 128-byte lines --------------
     {
       const float inv = 1.0f / l;
@@ -572,7 +469,7 @@ __global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __
 }
 
 // 1 = not served (shape outside the persistent kernel's LDS budget or 32-bit offsets)
-template <int NB>
+template <int NB, bool SHORT>
 int launch_persist(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, int n_frames, int tokens, int heads, float scale,
                    hipStream_t st) {
   const int64_t lds = (int64_t)4 * tokens * 128 + 2 * NB * 4096;
@@ -585,11 +482,11 @@ int launch_persist(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, i
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
     if (ncu <= 0) ncu = 256;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_persist_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_persist_kernel<NB, SHORT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int grid = ncu & ~7;  // a whole number of workgroups per XCD
   if (grid < 8) return 1;
-  hipLaunchKernelGGL((attn_mfma_persist_kernel<NB>), dim3(grid), dim3(512), (size_t)lds, st, static_cast<const bf16_t*>(qkv),
+  hipLaunchKernelGGL((attn_mfma_persist_kernel<NB, SHORT>), dim3(grid), dim3(512), (size_t)lds, st, static_cast<const bf16_t*>(qkv),
                      (uint32_t)(ld_qkv * 2), static_cast<bf16_t*>(out), (uint32_t)(ld_out * 2), tokens, heads, n_frames,
                      (uint32_t)qkv_bytes, (uint32_t)out_bytes, scale * 1.4426950408889634f);
   hipError_t e = hipGetLastError();
@@ -624,17 +521,25 @@ int launch(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, int n_fra
 }  // namespace
 
 
+int dfd_attention_mfma_xrow_try(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, int n_frames, int tokens, int heads,
+                                float scale, hipStream_t st);  // attention_mfma_xrow.hip
+
 int dfd_attention_mfma_try(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, int n_frames, int tokens, int heads,
                            float scale, hipStream_t st) {
   if ((ld_qkv % 8) != 0 || (ld_out % 4) != 0) return 1;
   // NB = ceil(tokens / 32) exactly: the kernels mask only their last key block
   if (tokens > 6 * 32 && tokens <= 7 * 32) {
     if (n_frames * heads >= 512) {
-      const int rc = launch_persist<7>(qkv, ld_qkv, out, ld_out, n_frames, tokens, heads, scale, st);
+      const int rc = tokens <= 6 * 32 + 8 ? launch_persist<7, true>(qkv, ld_qkv, out, ld_out, n_frames, tokens, heads, scale, st)
+                                          : launch_persist<7, false>(qkv, ld_qkv, out, ld_out, n_frames, tokens, heads, scale, st);
       if (rc <= 0) return rc;
     }
     return launch<7>(qkv, ld_qkv, out, ld_out, n_frames, tokens, heads, scale, st);
   }
-  if (tokens > 8 * 32 && tokens <= 9 * 32) return launch<9>(qkv, ld_qkv, out, ld_out, n_frames, tokens, heads, scale, st);
+  if (tokens > 8 * 32 && tokens <= 9 * 32) {
+    const int rc = dfd_attention_mfma_xrow_try(qkv, ld_qkv, out, ld_out, n_frames, tokens, heads, scale, st);  // 257 tokens, >= 512 items
+    if (rc <= 0) return rc;
+    return launch<9>(qkv, ld_qkv, out, ld_out, n_frames, tokens, heads, scale, st);
+  }
   return 1;
 }
