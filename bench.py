@@ -338,14 +338,23 @@ def main():
 
     host_ms = [0.0, 0.0]
 
+    PRIME_STEPS = 4
+
     def timed(fn, steps, profile):
-        if profile:  # dominant kernel: c_fc GEMM (M x 4D x D, QuickGELU epilogue); HIP events on the launch stream
-            capi.profile_gemm(epilogue=capi.EPI_BIAS_QUICKGELU)
+        # dominant kernel: c_fc GEMM (M x 4D x D, QuickGELU epilogue), HIP events around its launches on the launch stream.
+        # When the encoder's pass replays as one HIP graph there are no individual launches to bracket, so the LAST
+        # `prof_steps` steps of the timed region launch the encoder's kernels one by one and those launches are the ones
+        # timed (same kernels, same stream, inside the timed region; the steps are GPU-bound either way).
+        prof_steps = min(3, steps) if profile and det.static_graphs else (steps if profile else 0)
         barrier()
         t0 = time.perf_counter()
         c0 = time.process_time()
-        for _ in range(steps):
+        for i in range(steps):
+            if prof_steps and i == steps - prof_steps:
+                det.encoder_graph_pause = True
+                capi.profile_gemm(epilogue=capi.EPI_BIAS_QUICKGELU)
             fn()
+        det.encoder_graph_pause = False
         enq = time.perf_counter() - t0  # the host has enqueued everything (no sync inside a step)
         cpu = time.process_time() - c0  # CPU seconds of all threads of this process spent doing so
         barrier()
@@ -363,6 +372,11 @@ def main():
         det.calibrate_fp8(x[:2])
     det.train(args.mode == "train")
     step = train_step if args.mode == "train" else infer_step
+    # Setup, before the W warm-up steps the caller asked for: HIP graphs are captured the second time a signature is seen and
+    # the pipelined path alternates between two K/V sets, so four steps see every capture through (like the lazy
+    # initialisations of the first step, it is one-off work that does not belong to a step's time).
+    for _ in range(PRIME_STEPS):
+        step()
     for _ in range(args.warmup):
         step()
     graph_note = None
@@ -386,7 +400,8 @@ def main():
     fwd_only = None
     if args.mode == "train":  # informational: BASELINE configs[1], forward-only, outside the headline's timed region
         det.eval()
-        infer_step()
+        for _ in range(PRIME_STEPS):
+            infer_step()
         dt_i, _ = timed(infer_step, max(2, args.steps // 2), False)
         fwd_only = world * B * max(2, args.steps // 2) / dt_i
 
@@ -424,7 +439,7 @@ def main():
                                     f"BASELINE configs[1]: {args.arch} forward-only Detector.predict (inference.py path)")
                                    + f", {B} clips x {T} frames x 3x{res}x{res} per GPU, decode layers {det.layer_indices}, "
                                      f"random-init weights, inputs resident in HBM",
-                       "mode": args.mode, "adapter": args.adapter, "clips_per_gpu": B, "frames_per_clip": T, "hip_graphs": bool(det.static_graphs) and not det.decoder._graphs_failed and not (det.adapter is not None and det.adapter._graphs_failed), "pipelined_encoder": bool(det.pipeline_encoder), "frame_chunk": det.encoder.frame_chunk,
+                       "mode": args.mode, "adapter": args.adapter, "clips_per_gpu": B, "frames_per_clip": T, "hip_graphs": bool(det.static_graphs) and not det.decoder._graphs_failed and not (det.adapter is not None and det.adapter._graphs_failed), "encoder_graph": bool(det._enc_graphs) and not det._enc_graphs_failed, "pipelined_encoder": bool(det.pipeline_encoder), "frame_chunk": det.encoder.frame_chunk,
                        "streams": det.encoder.streams},
             "roofline": {"bound": "mfma", "kernel": "c_fc GEMM + QuickGELU (M=%d, N=%d, K=%d)" % (launch_m, 4 * width, width),
                          "achieved": round(achieved, 2) if achieved else None, "peak": peak, "unit": "TFLOP/s",

@@ -156,6 +156,16 @@ __device__ __forceinline__ void attn_pv(const f32x16 (&S)[NB], const unsigned ch
   }
 }
 
+// One 16-byte store per lane, scalar-offset field = 0.  With a REGISTER in that field the compiler's hazard recognizer
+// leaves out the wait states it otherwise puts between a store of more than 8 bytes per lane and a VALU write of the
+// store's data registers (LLVM, GCNHazardRecognizer::createsVALUHazard: "this hazard only exists if the instruction is not
+// using a register in the soffset field") — and on gfx950 the store had not always read its data by then: it went out
+// with the next instruction's result in its first data register for the lanes read last (round 3: 32 elements of a
+// 32 x 64 tile, sporadically, more often on the second wave of a SIMD).  tools/isa_lint.py checks every kernel for it.
+__device__ __forceinline__ void attn_store_line(v4i_t d, __amdgpu_buffer_rsrc_t srd, uint32_t off) {
+  __builtin_amdgcn_raw_buffer_store_b128(d, srd, off, 0, 0);
+}
+
 template <int N> __device__ __forceinline__ void attn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 }  // namespace

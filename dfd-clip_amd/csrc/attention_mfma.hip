@@ -457,8 +457,9 @@ __global__ __launch_bounds__(512) void attn_mfma_persist_kernel(const bf16_t* __
         const int rl = 8 * i + (lane >> 3), pos = lane & 7;
         const v4i_t d = *reinterpret_cast<const v4i_t*>(Qs + rl * 128 + ((pos ^ ((rl >> 1) & 7)) << 4));
         const int qq = qb * 32 + rl;
-        const uint32_t off = qq < tokens ? (uint32_t)qq * ldo + pos * 16 : 0xffffffffu;  // rows past the frame: dropped
-        __builtin_amdgcn_raw_buffer_store_b128(d, srdO, off, obase, 0);
+        // (the item's base goes into the lane offset, not into the scalar-offset field: see attn_store_line())
+        const uint32_t off = qq < tokens ? obase + (uint32_t)qq * ldo + pos * 16 : 0xffffffffu;  // rows past the frame: dropped
+        attn_store_line(d, srdO, off);
       }
     }
     }

@@ -6,12 +6,12 @@
 // 197-token kernel has) would halve the register budget of all of them.  So:
 //   * eight waves, one 32-query block each (queries 0..255), all of them full;
 //   * query 256, the extra row, is spread over the workgroup so that no wave carries a second round:
-//       - scores: wave w multiplies key block w (wave 4: block 8 as well) with the operands of the first product SWAPPED
+//       - scores: wave w multiplies key block w (wave 0: block 8 as well) with the operands of the first product SWAPPED
 //         (S[q][key] instead of Sᵀ[key][q]; every row of the A operand is the one query): four MFMAs, and each lane
 //         ends up with the score of ITS key, which goes to LDS;
-//       - softmax: wave 4 — 9 exponentials per lane instead of 144, the sums run across lanes in the order the
+//       - softmax: wave 0 — 9 exponentials per lane instead of 144, the sums run across lanes in the order the
 //         register form uses; P (bf16) and 1/l go to LDS;
-//       - second product: waves 5 and 6 take one 32-channel half each, riding along their own second product (one more
+//       - second product: waves 1 and 2 take one 32-channel half each, riding along their own second product (one more
 //         MFMA per step over the V fragments already in registers; all 32 P columns equal, column 0 is stored).
 //     The hand-overs are two counters in LDS (ds_add by the producer behind its writes — a wave's LDS operations
 //     execute in order; the consumer polls; it practically never has to, the producers are a phase ahead);
@@ -25,6 +25,7 @@
 // vmcnt is counted by hand: memory operations retire in order, so "my DMAs and Q loads have landed" is "at most the
 // stores issued after them are still in flight" (4 per wave, 5 for the two waves that also store half of the extra
 // row; all of them in range — a fully out-of-range store would retire early and break the count).
+// Stores go through attn_store_line() (no register in the scalar-offset field: attention_common.hpp says why).
 #include "attention_common.hpp"
 
 namespace {
@@ -44,14 +45,8 @@ constexpr int X_CNT_P = 1796;      // softmax hand-overs so far (1 per item)
 constexpr int X_Q = 2048;          // its Q row, one 128-byte image per item parity
 constexpr int X_BYTES = 2560;
 constexpr int XROW_LDS = 4 * IMG + NW * STG + X_BYTES;
-// Which waves carry the extra row: its softmax on wave 4, the halves of its second product on waves 5 and 6.
-// OPEN ISSUE (round 3): with these roles on waves 0, 1, 2 the waves sharing their SIMDs (4, 5, 6) sporadically stored
-// zeros in 32 elements of their own tile (channels 32 + 8g + {0,1} of queries 1, 3, 5, 7 of the block; hundreds of items
-// in 1,280).  Moving the LDS areas did not move the pattern; nothing in the ISA explains it; no mechanism was tested.
-// With the roles on the second wave of each SIMD: 0 mismatches against the per-item kernel in 16,640 items
-// (tools/lab/attn_probe.py; tests/test_hip_kernels.py::test_encoder_attention_257_tokens_stress).  A workaround found
-// by bisection, not a diagnosis.
-constexpr int XW_SOFTMAX = 4, XW_PV0 = 5;
+// Which waves carry the extra row: its softmax on wave 0, the halves of its second product on waves 1 and 2.
+constexpr int XW_SOFTMAX = 0, XW_PV0 = 1;
 
 __device__ __forceinline__ uint32_t lds_addr(const unsigned char* p) { return (uint32_t)(uintptr_t)(lds_ptr_t)(const_cast<unsigned char*>(p)); }
 // LDS stores in the middle of an item are inline asm: in front of an LDS store it knows about the compiler puts a vmcnt(0)
@@ -303,7 +298,7 @@ __global__ __launch_bounds__(512) void attn_mfma_xrow_kernel(const bf16_t* __res
           const int rl = 8 * i + (lane >> 3), pos = lane & 7;
           const v4i_t d = *reinterpret_cast<const v4i_t*>(stg + rl * 128 + ((pos ^ ((rl >> 1) & 7)) << 4));
           const uint32_t qq = (uint32_t)(wave * 32 + 16 * pass + rl);
-          __builtin_amdgcn_raw_buffer_store_b128(d, srdO, qq * ldo + pos * 16, obase, 0);
+          attn_store_line(d, srdO, obase + qq * ldo + pos * 16);
         }
       }
     }
@@ -326,7 +321,7 @@ __global__ __launch_bounds__(512) void attn_mfma_xrow_kernel(const bf16_t* __res
       asm volatile("" ::: "memory");
       if (lo < 4) {
         const v4i_t d = *reinterpret_cast<const v4i_t*>(stg + lo * 16);
-        __builtin_amdgcn_raw_buffer_store_b128(d, srdO, (uint32_t)(tokens - 1) * ldo + dt * 64 + lo * 16, obase, 0);
+        attn_store_line(d, srdO, obase + (uint32_t)(tokens - 1) * ldo + dt * 64 + lo * 16);
       }
     }
     have = have_next;

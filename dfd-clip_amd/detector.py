@@ -203,7 +203,27 @@ class ClipTransform:
 
 class Detector(RuntimeStateMixin, nn.Module):
     _RUNTIME_STATE = {"_kv_static": None, "_kv_cache": {}, "_enc_stream": None, "_pipe_events": [[], []], "_pipe_step": 0, "_pos_snap": None,
-                      "_drop_master": None}
+                      "_drop_master": None, "_enc_graphs": {}, "_enc_graph_seen": {}, "_enc_graphs_failed": None, "_all_params": None}
+
+    def _apply(self, fn, *a, **k):
+        self._all_params = None  # (.to() / .half() may re-create parameter objects)
+        return super()._apply(fn, *a, **k)
+
+    def zero_grad(self, set_to_none=True):
+        """`nn.Module.zero_grad` without the walk over the module tree: the parameter objects are created once in
+        `__init__` (the list is rebuilt by `_apply` / `load_state_dict` / `invalidate_caches`), and collecting the ~230 of
+        them through `named_parameters` every call cost 0.6 ms of host time — the reference's trainer calls
+        `model.zero_grad()` twice per step (`src/trainer.py:110`, `:177`).  Every parameter is still looked at."""
+        if self._all_params is None:
+            self._all_params = list(self.parameters())
+        for p in self._all_params:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.detach_()
+                    p.grad.requires_grad_(False)
+                    p.grad.zero_()
 
     def invalidate_caches(self):
         """Drop every device-side copy derived from the parameters (bf16 encoder weights, transposed decoder
@@ -211,6 +231,8 @@ class Detector(RuntimeStateMixin, nn.Module):
         automatically; call this after writing parameters in place by other means (`dist.broadcast_parameters`)."""
         self.encoder.invalidate()
         self.decoder.invalidate_caches()
+        self._enc_graphs, self._enc_graph_seen = {}, {}
+        self._all_params = None
         if self.adapter is not None:
             self.adapter.invalidate_caches()
 
@@ -263,6 +285,9 @@ class Detector(RuntimeStateMixin, nn.Module):
         # 224 CUs as on 256, so it is free for the encoder; forward 912 -> 917.6 clips/s, alternating runs on one box)
         self.pipeline_spare_in_eval = True
         self._enc_stream = None
+        self._enc_graphs, self._enc_graph_seen, self._enc_graphs_failed = {}, {}, None
+        self.encoder_graph_pause = False  # True: launch the encoder's kernels one by one (per-kernel HIP-event timing, `bench.py`)
+        self._all_params = None
         self._pipe_events = [[], []]
         self._pipe_step = 0
         self._pos_snap = None
@@ -434,7 +459,11 @@ class Detector(RuntimeStateMixin, nn.Module):
         self.encoder.spare_window_layers = self.pipeline_collective_layers if torch.is_grad_enabled() and self.training else 0
         try:
             with torch.cuda.stream(E):
-                kv = finish(self.encoder.extract_kv(x.flatten(0, 1), self.layer_indices, t, pos, pos_ready=pos_ready, **kw))
+                frames = x.flatten(0, 1)
+                if not (in_place and self.static_graphs and self._replay_encoder(frames, t, out)):
+                    self.encoder.extract_kv(frames, self.layer_indices, t, pos, pos_ready=pos_ready, **kw)
+                D_ = self.encoder.width
+                kv = finish((out[:, :, 1:, D_:2 * D_], out[:, :, 1:, 2 * D_:]) if in_place else out)
         finally:
             self.encoder.spare_cus = 0
         x.record_stream(E)
@@ -442,6 +471,44 @@ class Detector(RuntimeStateMixin, nn.Module):
         events = [torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()]  # forward, decoder bwd, adapter bwd
         self._pipe_events[slot] = events
         return kv, (cur, *events)
+
+    def _replay_encoder(self, frames, t, out):
+        """The frozen encoder's pass as ONE HIP graph launch (static_graphs + pipelined + K/V in place): ~110 kernel
+        launches per pass cost 1.2-1.4 ms of host time, and a training step whose host falls behind (a loaded machine:
+        enqueue 6 -> 9 ms) was measured to lose 13 % of its throughput to the bubbles.  A graph is captured for an
+        (input address, K/V set, launch policy) signature the second time it is seen in a row of calls — a loader that hands
+        out a new buffer every step never repeats one and stays on eager launches; static or recycled batches (what
+        `inputs_ready` is for) replay.  Nothing in the pass depends on host state: weights frozen, no dropout, no waits
+        (the positional embedding is added by the decoder in this mode).  Returns False when the caller has to launch."""
+        enc = self.encoder
+        if self._enc_graphs_failed or self.encoder_graph_pause or enc.streams != 1:
+            return False
+        key = (frames.data_ptr(), tuple(frames.shape), frames.dtype, out.data_ptr(), t, tuple(self.layer_indices), id(enc._prepare()),
+               enc.precision, enc.frame_chunk, enc.spare_cus, enc.spare_layers, enc.spare_window_layers)
+        g = self._enc_graphs.get(key)
+        if g is None:
+            seen = self._enc_graph_seen.get(key, 0) + 1
+            self._enc_graph_seen = {key: seen} if len(self._enc_graph_seen) > 16 else {**self._enc_graph_seen, key: seen}
+            if seen < 2:
+                return False  # (this eager pass is also the warm-up a capture needs: lazy initialisations, fp8 calibration)
+            while len(self._enc_graphs) >= 4:
+                torch.cuda.synchronize()  # a replay of the entry may still be executing
+                self._enc_graphs.pop(next(iter(self._enc_graphs)))
+            torch.cuda.synchronize()
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    enc.extract_kv(frames, self.layer_indices, t, None, in_place=out)
+            except Exception as e:  # capture is an optimisation: a runtime that refuses it leaves the eager launches
+                self._enc_graphs_failed = f"{type(e).__name__}: {e}"
+                logging.warning("encoder: HIP graph capture failed, staying on eager launches (%s)", self._enc_graphs_failed)
+                torch.cuda.synchronize()
+                return False
+            self._enc_graphs[key] = g
+        else:
+            self._enc_graphs[key] = self._enc_graphs.pop(key)  # most recently used last
+        g.replay()
+        return True
 
     def predict(self, x, m, with_video_features=False, with_adapt_features=False, train=False):
         """x [B,T,3,R,R], m [B,T] bool -> (task_logits list of [B,out_dim] with L2 norm 5, features)."""

@@ -461,6 +461,39 @@ def test_pipelined_encoder_matches_eager_training(graphs, name):
         assert torch.equal(det_p(x, [y], m, single_task=0)[1][0], det_e.eval()(x, [y], m, single_task=0)[1][0])
 
 
+def test_pipelined_encoder_pass_replays_as_one_graph():
+    """static_graphs + pipeline_encoder + K/V in place on RECURRING input buffers (two batches alternating, as a loader
+    with recycled pinned/device buffers hands them out): from the second sighting of an (input, K/V set) pair the
+    frozen encoder's pass is one HIP graph launch.  Eight steps give the plain path's losses, gradients and parameters
+    bit for bit, and the graphs were really captured and replayed."""
+    import copy
+    case = build_case("small")
+    det_e = make_detector(case, "bf16")
+    det_p = copy.deepcopy(det_e)
+    det_p.pipeline_encoder, det_p.inputs_ready, det_p.static_graphs = True, True, True
+    x, m, y = case["x"].cuda(), case["m"].cuda(), case["y"].cuda()
+    a, b = (x.contiguous(), m, y), ((x * 0.5).flip(0).contiguous(), m.flip(0).contiguous(), y.flip(0).contiguous())
+    torch.cuda.synchronize()
+    opt_e, opt_p = det_e.configure_optimizers(0.01), det_p.configure_optimizers(0.01)
+    for step in range(8):
+        xs, ms, ys = (a, b)[step % 2] if step < 6 else a  # ... and the same batch three times in a row at the end
+        res = []
+        for det, opt in ((det_e, opt_e), (det_p, opt_p)):
+            det.train()
+            det.zero_grad()
+            losses, logits, other = det(xs, [ys], ms, train=True, single_task=0)
+            (losses[0].mean() + sum(other.values())).backward()
+            res.append((losses[0].detach().clone(), {n: p.grad.detach().clone() for n, p in det.named_parameters() if p.grad is not None}))
+            opt.step()
+        assert torch.equal(res[0][0], res[1][0]), f"step {step}: losses differ"
+        for n in res[0][1]:
+            assert torch.equal(res[0][1][n], res[1][1][n]), f"step {step}: gradient of {n} differs"
+    assert det_p._enc_graphs_failed is None and len(det_p._enc_graphs) >= 2, (det_p._enc_graphs_failed, len(det_p._enc_graphs))
+    assert not det_e._enc_graphs
+    for (n, pe), (_, pp) in zip(det_e.named_parameters(), det_p.named_parameters()):
+        assert torch.equal(pe, pp), n
+
+
 @pytest.mark.parametrize("graphs", [False, True])
 def test_pipelined_encoder_with_changing_batch_size(graphs):
     """The pipelined path keeps persistent K/V buffer sets per batch shape; a shape change (the last batch of an epoch)

@@ -553,9 +553,9 @@ def test_encoder_attention_persistent_kernel_matches_per_item_kernel(capi, n, to
 def test_encoder_attention_257_tokens_stress(capi):
     """ViT-L/14's shape at BASELINE configs[3] size (240 frames x 16 heads = 3,840 items of 257 tokens) through the
     persistent 257-token kernel (attention_mfma_xrow.hip), three launches on fresh inputs, each compared bit for bit with
-    the per-item kernel.  The kernel hands its extra row over between waves through LDS counters, and an earlier
-    placement of those roles corrupted other waves' tiles sporadically for a reason that was never found (see the OPEN
-    ISSUE note in the source): this is the case that would show it."""
+    the per-item kernel.  This is the case that showed round 3's store hazard (a 16-byte-per-lane store with a register
+    in its scalar-offset field going out with the next instruction's result in its first data register: sporadic, 32
+    elements of a tile at a time; csrc/attention_common.hpp, tools/isa_lint.py)."""
     n, tokens, heads = 240, 257, 16
     D = heads * 64
     for seed in (31, 32, 33):

@@ -255,3 +255,15 @@ def test_load_clip_visual_rejects_torchscript_archive_with_instructions(tmp_path
         load_clip_visual(bad, "bf16")
     with pytest.raises(RuntimeError, match="not found"):
         load_clip_visual("ViT-Z/99", "bf16")
+
+
+def test_isa_lint_no_register_scalar_offset_on_wide_stores():
+    """tools/isa_lint.py over every kernel source: no vector store of more than 8 bytes per lane carries a register in its
+    scalar-offset field (the form the compiler's store-data hazard handling skips; on gfx950 it corrupted output tiles
+    sporadically in round 3).  Compiles the device code to assembly with hipcc: no GPU involved."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    assert lint.main([]) == 0

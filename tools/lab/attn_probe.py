@@ -14,7 +14,10 @@ tok = int(sys.argv[2]) if len(sys.argv) > 2 else 257
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 capi.load_library()
 torch.manual_seed(5)
-qkv = torch.randn(n * tok, 3 * H * 64, device="cuda").to(torch.bfloat16)
+qkv = torch.randn(n * tok, 3 * H * 64, device="cuda")
+scale = float(os.environ.get("PROBE_QK_SCALE", "1"))  # > 1: peaky softmax rows (lab tool only)
+qkv[:, :2 * H * 64] *= scale
+qkv = qkv.to(torch.bfloat16)
 whole = torch.empty(n * tok, H * 64, device="cuda", dtype=torch.bfloat16)
 capi.attention_fwd(qkv, whole, n, tok, H)
 parts = torch.empty_like(whole)
