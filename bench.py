@@ -17,8 +17,17 @@ Prints ONE JSON line on rank 0 with the whole-job clips/s plus
                  algorithmic FLOPs per launch / its average launch duration measured with HIP
                  events on the launch stream during the timed steps, against the 2.5 PFLOP/s
                  dense bf16 MFMA peak;
+                 (with HIP graphs on, the encoder's pass is one graph launch; the last three timed steps
+                 launch its kernels one by one so that these launches can be bracketed — same kernels,
+                 same stream, inside the timed region);
   cpu_baseline — the CPU oracle (this repo's PyTorch-CPU port of the reference path) timed on
                  this host on a bounded sample (one 30-frame clip), rank 0, N=1 only.
+Host figures: `host_enqueue_ms_each_step` is the wall time the host spent inside each timed step's calls,
+`host_enqueue_ms_median` their median, `host_enqueue_ms_per_step` their mean and `host_cpu_ms_per_step` the CPU
+seconds of all threads over the region.  A step that replays graphs is enqueued in about a millisecond, so the host
+runs many steps ahead of the GPU and one of the kernel-by-kernel steps at the end typically blocks on the runtime's
+queue depth for a few GPU steps (a 70 ms entry in the list, busy-waiting): that is back-pressure, not work — the
+median is the figure that says what a step costs the host.
 """
 import argparse
 import json
@@ -337,6 +346,7 @@ def main():
         torch.cuda.synchronize()
 
     host_ms = [0.0, 0.0]
+    host_steps = []  # host milliseconds of each timed step's enqueue (the last ones launch the encoder kernel by kernel)
 
     PRIME_STEPS = 4
 
@@ -349,12 +359,16 @@ def main():
         barrier()
         t0 = time.perf_counter()
         c0 = time.process_time()
+        per_step = []
         for i in range(steps):
             if prof_steps and i == steps - prof_steps:
                 det.encoder_graph_pause = True
                 capi.profile_gemm(epilogue=capi.EPI_BIAS_QUICKGELU)
+            ts = time.perf_counter()
             fn()
+            per_step.append((time.perf_counter() - ts) * 1e3)
         det.encoder_graph_pause = False
+        host_steps[:] = per_step
         enq = time.perf_counter() - t0  # the host has enqueued everything (no sync inside a step)
         cpu = time.process_time() - c0  # CPU seconds of all threads of this process spent doing so
         barrier()
@@ -397,6 +411,7 @@ def main():
                 step()
     dt, spans = timed(step, args.steps, True)
     host_enqueue_ms, host_cpu_ms = host_ms
+    host_step_ms = [round(v, 2) for v in host_steps]
     fwd_only = None
     if args.mode == "train":  # informational: BASELINE configs[1], forward-only, outside the headline's timed region
         det.eval()
@@ -430,7 +445,7 @@ def main():
         line = {
             "metric": f"1-sec clips/sec (30x224x224 frames) {args.arch}", "value": round(world * B * args.steps / dt, 3),
             "unit": "clips/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(host_enqueue_ms, 3), "host_cpu_ms_per_step": round(host_cpu_ms, 3),
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(host_enqueue_ms, 3), "host_cpu_ms_per_step": round(host_cpu_ms, 3), "host_enqueue_ms_median": round(sorted(host_step_ms)[len(host_step_ms) // 2], 3) if host_step_ms else None, "host_enqueue_ms_each_step": host_step_ms,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic" if args.ingest == "f32" else "synthetic uint8 frames %dx%d" % tuple(x.shape[-2:]),
             "config": {"workload": (f"BASELINE configs[2] (fwd+bwd): {args.arch} train step = frozen-encoder forward + decoder "

@@ -483,9 +483,18 @@ class Detector(RuntimeStateMixin, nn.Module):
         enc = self.encoder
         if self._enc_graphs_failed or self.encoder_graph_pause or enc.streams != 1:
             return False
-        key = (frames.data_ptr(), tuple(frames.shape), frames.dtype, out.data_ptr(), t, tuple(self.layer_indices), id(enc._prepare()),
-               enc.precision, enc.frame_chunk, enc.spare_cus, enc.spare_layers, enc.spare_window_layers)
-        g = self._enc_graphs.get(key)
+        if enc.frame_chunk:
+            return False
+        key = (frames.data_ptr(), tuple(frames.shape), frames.dtype, out.data_ptr(), t, tuple(self.layer_indices),
+               enc.precision, enc.spare_cus, enc.spare_layers, enc.spare_window_layers, enc.deferred_residual,
+               tuple(sorted(enc.stream_out.items())), tuple(sorted(enc.spare_gemms.items())))
+        guard = enc.graph_guard(frames.shape[0])
+        ent = self._enc_graphs.get(key)
+        if ent is not None and not all(a is b for a, b in zip(ent[1], guard)):
+            torch.cuda.synchronize()  # (a replay may still be executing on the buffers the entry keeps alive)
+            del self._enc_graphs[key]
+            ent = None
+        g = None if ent is None else ent[0]
         if g is None:
             seen = self._enc_graph_seen.get(key, 0) + 1
             self._enc_graph_seen = {key: seen} if len(self._enc_graph_seen) > 16 else {**self._enc_graph_seen, key: seen}
@@ -504,7 +513,7 @@ class Detector(RuntimeStateMixin, nn.Module):
                 logging.warning("encoder: HIP graph capture failed, staying on eager launches (%s)", self._enc_graphs_failed)
                 torch.cuda.synchronize()
                 return False
-            self._enc_graphs[key] = g
+            self._enc_graphs[key] = (g, guard)
         else:
             self._enc_graphs[key] = self._enc_graphs.pop(key)  # most recently used last
         g.replay()

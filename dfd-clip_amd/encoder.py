@@ -303,6 +303,13 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
             self._ws[key] = ws
         return ws
 
+    def graph_guard(self, n):
+        """The objects whose device buffers a captured pass over `n` frames has baked in as addresses: the prepared weights,
+        the fp8 scale tables, the workspace.  A graph keeps this tuple (so none of them can be freed under it) and is
+        valid only while the encoder would still use the very same objects (`is`) — `.to()`, `load_state_dict`, a new
+        calibration or an evicted workspace make it stale."""
+        return (self._prepare(), self._fp8_layers() if self.precision == "fp8" else None, self._workspace(n, 1, slot=0))
+
     # ---- kernels sequence ---------------------------------------------------------------
     def _as_frames(self, x):
         """f32 frames [N,3,R,R] already transformed, or uint8 frames [N,3,H,W] straight from the

@@ -492,6 +492,20 @@ def test_pipelined_encoder_pass_replays_as_one_graph():
     assert not det_e._enc_graphs
     for (n, pe), (_, pp) in zip(det_e.named_parameters(), det_p.named_parameters()):
         assert torch.equal(pe, pp), n
+    # new encoder weights: the captured passes are stale (they carry the old weight buffers as addresses) and must not be
+    # replayed — the next steps follow the new weights, again bit for bit with the plain path
+    sd = {k: (v * 1.01 if k.endswith("mlp.c_fc.weight") else v) for k, v in det_e.encoder.state_dict().items()}
+    for det in (det_e, det_p):
+        det.encoder.load_state_dict(sd)
+    for step in range(3):
+        res = []
+        for det, opt in ((det_e, opt_e), (det_p, opt_p)):
+            det.zero_grad()
+            losses, _, other = det(a[0], [a[2]], a[1], train=True, single_task=0)
+            (losses[0].mean() + sum(other.values())).backward()
+            res.append(losses[0].detach().clone())
+            opt.step()
+        assert torch.equal(res[0], res[1]), f"after new encoder weights, step {step}: losses differ"
 
 
 @pytest.mark.parametrize("graphs", [False, True])
