@@ -28,6 +28,7 @@ class DfdError(RuntimeError):
 
 
 GEMM_STREAM_OUT = 1
+GEMM_SPARE_IF_FREE = 2  # spare_cus is honoured only where it costs this shape no extra round of tiles
 
 
 class GemmExtra(Structure):
@@ -260,7 +261,7 @@ def profile_gemm_collect():
 
 
 def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_export=None, v_export=None, tokens=0,
-         frames_per_clip=0, residual=None, qkv_first=0, drop=None, stream_out=False, spare_cus=0, tile_blocks=0):
+         frames_per_clip=0, residual=None, qkv_first=0, drop=None, stream_out=False, spare_cus=0, tile_blocks=0, spare_if_free=False):
     """c = epilogue(a[M,K] @ w[N,K]^T).  `m` limits the rows used (buffers may be over-allocated)."""
     _dev(a, w, c, bias, pos, cls, k_export, v_export, residual)
     assert a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1 and c.stride(1) == 1
@@ -271,7 +272,7 @@ def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_ex
     assert drop is None or epilogue == EPI_RESIDUAL_POS
     extra = GemmExtra(_ptr(pos).value, _ptr(cls).value, _ptr(k_export).value, _ptr(v_export).value, tokens, frames_per_clip,
                       _ptr(residual).value, qkv_first, drop.rng.data_ptr() if drop is not None and drop.p > 0 else None,
-                      drop.site if drop is not None else 0, drop.p if drop is not None else 0.0, (GEMM_STREAM_OUT if stream_out else 0) | ((int(spare_cus) & 0xff) << 8) | ((int(tile_blocks) & 0xf) << 16))
+                      drop.site if drop is not None else 0, drop.p if drop is not None else 0.0, (GEMM_STREAM_OUT if stream_out else 0) | (GEMM_SPARE_IF_FREE if spare_if_free else 0) | ((int(spare_cus) & 0xff) << 8) | ((int(tile_blocks) & 0xf) << 16))
     timed = _profile["epilogue"] == epilogue
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -285,7 +286,7 @@ def gemm(a, w, c, bias=None, epilogue=EPI_BIAS, m=None, pos=None, cls=None, k_ex
 
 
 def gemm_fp8(a, w, c, col_scale, bias=None, epilogue=EPI_BIAS, m=None, out_inv_scale=0.0, pos=None, k_export=None, v_export=None,
-             tokens=0, frames_per_clip=0, qkv_first=0, stream_out=False, spare_cus=0):
+             tokens=0, frames_per_clip=0, qkv_first=0, stream_out=False, spare_cus=0, spare_if_free=False):
     """c = epilogue((a[M,K] @ w[N,K]^T) * col_scale + bias) on e4m3 operands (uint8 / float8_e4m3fn storage);
     c bf16, or e4m3 bytes of result * out_inv_scale."""
     _dev(a, w, c, col_scale, bias, pos, k_export, v_export)
@@ -296,7 +297,7 @@ def gemm_fp8(a, w, c, col_scale, bias=None, epilogue=EPI_BIAS, m=None, out_inv_s
     assert a.shape[1] == K and col_scale.numel() == N
     c_dtype = FP8 if c.element_size() == 1 else _DTYPE[c.dtype]
     extra = GemmExtra(_ptr(pos).value, None, _ptr(k_export).value, _ptr(v_export).value, tokens, frames_per_clip, None, qkv_first,
-                      None, 0, 0.0, (GEMM_STREAM_OUT if stream_out else 0) | ((int(spare_cus) & 0xff) << 8))
+                      None, 0, 0.0, (GEMM_STREAM_OUT if stream_out else 0) | (GEMM_SPARE_IF_FREE if spare_if_free else 0) | ((int(spare_cus) & 0xff) << 8))
     timed = _profile["epilogue"] == epilogue
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

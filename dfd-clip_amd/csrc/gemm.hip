@@ -302,6 +302,7 @@ static int fill_extra(GemmArgs& a, int epilogue, const dfd_gemm_extra* extra, in
     a.qkv_first = epilogue == DFD_EPI_QKV_EXPORT ? extra->qkv_first : 0;
     a.stream_out = (extra->flags & DFD_GEMM_STREAM_OUT) ? 1 : 0;
     a.spare_cus = (int)((extra->flags >> DFD_GEMM_SPARE_CUS_SHIFT) & 0xff);
+    a.spare_if_free = (extra->flags & DFD_GEMM_SPARE_IF_FREE) ? 1 : 0;
     a.tile_rows = 32 * (int)((extra->flags >> DFD_GEMM_TILE_BLOCKS_SHIFT) & 0xf);
     DFD_REQUIRE(a.tile_rows == 0 || a.tile_rows == 224 || a.tile_rows == 256, "dfd_gemm: tile blocks must be 0, 7 or 8");
     if (epilogue == DFD_EPI_RESIDUAL_POS && extra->drop_rng && extra->drop_p > 0.f) {

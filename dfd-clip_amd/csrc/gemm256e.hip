@@ -717,6 +717,15 @@ int launch256e(const GemmArgs& a_in, hipStream_t st) {
   }
   int cus = n_cu - a.spare_cus;
   cus = cus < n_cu / 2 ? n_cu / 2 : cus;
+  if (a.spare_cus > 0 && a.spare_if_free) {
+    // a request, not an order: honoured where the rounds of tiles (at the better of the two tile heights) stay the same
+    auto cost = [&](int c) {
+      auto r = [&](int rows) { return (double)((((a.M + rows - 1) / rows) * tiles_n + c - 1) / c); };
+      const double r256 = r(256), r224 = r(224) * 0.97;
+      return (F8 || EPI == DFD_EPI_RESIDUAL_POS) ? (EPI == DFD_EPI_RESIDUAL_POS ? r224 : r256) : (r224 < r256 ? r224 : r256);
+    };
+    if (cost(cus) > cost(n_cu)) cus = n_cu;
+  }
   // tile height: the one with the least (rounds of tiles) x (cost of a tile).  A 224-row tile saves the MFMA and
   // epilogue work of 32 rows but stages as many bytes as a 256-row one, and the loop is bound by that staging:
   // measured on the four ViT-B/16 shapes it costs 0.97 of a full tile, so it wins only where it saves a whole

@@ -17,6 +17,7 @@ struct GemmArgs {
   int qkv_first;  // QKV_EXPORT: first column block present (0 = q, 1 = k)
   int stream_out; // DFD_GEMM_STREAM_OUT: non-temporal output stores
   int spare_cus;  // persistent kernel: compute units left free for other streams
+  int spare_if_free;  // DFD_GEMM_SPARE_IF_FREE: ... only where that costs no extra round of tiles
   int tile_rows;  // persistent kernel: 0 = choose, 224 / 256 = force that tile height (lab, tests)
   DfdDrop drop;   // RESIDUAL_POS: dropout on the accumulator (element index row*N + col); thr16 == 0: none
   FastDiv div_tokens, div_frames;  // persistent kernel, QKV_EXPORT: row -> (frame, token), frame -> frame % T

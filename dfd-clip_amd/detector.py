@@ -457,6 +457,7 @@ class Detector(RuntimeStateMixin, nn.Module):
         self.encoder.spare_cus = spare if (torch.is_grad_enabled() and self.training) or self.pipeline_spare_in_eval else 0
         self.encoder.spare_layers = self.pipeline_spare_layers
         self.encoder.spare_window_layers = self.pipeline_collective_layers if torch.is_grad_enabled() and self.training else 0
+        self.encoder.spare_if_free = not (torch.is_grad_enabled() and self.training)
         try:
             with torch.cuda.stream(E):
                 frames = x.flatten(0, 1)
@@ -486,7 +487,7 @@ class Detector(RuntimeStateMixin, nn.Module):
         if enc.frame_chunk:
             return False
         key = (frames.data_ptr(), tuple(frames.shape), frames.dtype, out.data_ptr(), t, tuple(self.layer_indices),
-               enc.precision, enc.spare_cus, enc.spare_layers, enc.spare_window_layers, enc.deferred_residual,
+               enc.precision, enc.spare_cus, enc.spare_layers, enc.spare_window_layers, enc.spare_if_free, enc.deferred_residual,
                tuple(sorted(enc.stream_out.items())), tuple(sorted(enc.spare_gemms.items())))
         guard = enc.graph_guard(frames.shape[0])
         ent = self._enc_graphs.get(key)

@@ -154,6 +154,10 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         # the gradient all-reduce of the previous step (an RCCL kernel on the caller's stream) lands in that window, and a
         # persistent GEMM that holds all 256 CUs would make its workgroups queue for a whole GEMM each
         self.spare_window_layers = 0
+        # True: a GEMM outside the collective's window leaves the spare CUs only where that costs its shape no extra round of
+        # tiles.  `Detector._encode` clears it for training passes: there the decoder's backward beside the encoder is worth
+        # a fifth round of ViT-L/14's c_proj (A/B, B8xT30: train 201.5 binding vs 200.0 if-free; forward 209.6 vs 213.0)
+        self.spare_if_free = True
 
     # ---- derived device-side operands ---------------------------------------------------
     @property
@@ -369,7 +373,7 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
                                out_inv_scale=inv)
             ws["pending"] = 0
 
-    def _residual(self, ws, a, w, b, M, spare_cus=0):
+    def _residual(self, ws, a, w, b, M, spare_cus=0, spare_if_free=False):
         """x = x + Linear(a) (model.py:222-223).  fp32 path: read-modify-write of x in the GEMM
         epilogue.  bf16 path: the GEMM stores its output as a bf16 delta (plain store epilogue, a
         quarter of the epilogue bytes) and the add is deferred to the LayerNorm that follows."""
@@ -377,7 +381,7 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
             pend = ws.get("pending", 0)
             assert pend < 2
             capi.gemm(a, w, ws["delta2" if pend else "delta"], b, capi.EPI_BIAS, m=M, stream_out=self.stream_out["proj" if pend else "out"],
-                      spare_cus=spare_cus)
+                      spare_cus=spare_cus, spare_if_free=spare_if_free)
             ws["pending"] = pend + 1
         else:
             capi.gemm(a, w, ws["x"], b, capi.EPI_BIAS_RESIDUAL, m=M)
@@ -404,11 +408,14 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         sp_all = self.spare_cus if bp["idx"] < self.spare_window_layers else 0
         sg = self.spare_gemms
         sp_qkv, sp_out, sp_fc, sp_proj = (max(sp_all, sp if sg[k] else 0) for k in ("qkv", "out", "fc", "proj"))
+        # outside the collective's window the spare CUs are a request: a GEMM leaves them only where that costs its shape no
+        # extra round of tiles (ViT-B/16's c_proj: 5 rounds on 224 CUs as on 256; ViT-L/14's would need 5 instead of 4)
+        free = sp_all == 0 and self.spare_if_free
         D = self.width
         # q | k | v projection (+ K/V export); the last tapped layer computes only the K and V thirds
         first = 1 if kv_only else 0
         rows = slice(D, None) if first else slice(None)
-        kw = dict(m=M, tokens=self.tokens, qkv_first=first, stream_out=so["qkv"], spare_cus=sp_qkv)
+        kw = dict(m=M, tokens=self.tokens, qkv_first=first, stream_out=so["qkv"], spare_cus=sp_qkv, spare_if_free=free)
         if export is not None:
             kw.update(pos=export[2], k_export=export[0], v_export=export[1], frames_per_clip=export[3])
         if f8 is not None:
@@ -422,23 +429,23 @@ class VisionTransformer(RuntimeStateMixin, nn.Module):
         if kv_only:
             return
         capi.attention_fwd(qkv, ws["mix"], n, self.tokens, self.heads)
-        self._residual(ws, ws["mix"], bp["w_out"], bp["b_out"], M, spare_cus=sp_out)
+        self._residual(ws, ws["mix"], bp["w_out"], bp["b_out"], M, spare_cus=sp_out, spare_if_free=free)
         if f8 is not None:
             self._ln(ws, bp["ln2"], M, store=False, q=f8["h2_inv"])
             capi.gemm_fp8(ws["h8"], bp["w_fc8"], ws["u8"], f8["cs_fc"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M,
-                          out_inv_scale=f8["u_inv"], stream_out=so["fc"], spare_cus=sp_fc)
+                          out_inv_scale=f8["u_inv"], stream_out=so["fc"], spare_cus=sp_fc, spare_if_free=free)
             pend = ws.get("pending", 0)  # c_proj: the second deferred residual of the block (see `_residual`)
             capi.gemm_fp8(ws["u8"], bp["w_proj8"], ws["delta2" if pend else "delta"], f8["cs_proj"], bp["b_proj"], capi.EPI_BIAS, m=M,
-                          stream_out=so["proj"], spare_cus=sp_proj)
+                          stream_out=so["proj"], spare_cus=sp_proj, spare_if_free=free)
             ws["pending"] = pend + 1
         else:
             self._ln(ws, bp["ln2"], M, store=False)
             if calib is not None:
                 calib.append(ws["h"][:M].abs().max())
-            capi.gemm(ws["h"], bp["w_fc"], ws["u"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M, stream_out=so["fc"], spare_cus=sp_fc)
+            capi.gemm(ws["h"], bp["w_fc"], ws["u"], bp["b_fc"], capi.EPI_BIAS_QUICKGELU, m=M, stream_out=so["fc"], spare_cus=sp_fc, spare_if_free=free)
             if calib is not None:
                 calib.append(ws["u"][:M].abs().max())
-            self._residual(ws, ws["u"], bp["w_proj"], bp["b_proj"], M, spare_cus=sp_proj)
+            self._residual(ws, ws["u"], bp["w_proj"], bp["b_proj"], M, spare_cus=sp_proj, spare_if_free=free)
 
     @torch.no_grad()
     def forward(self, x, with_out=False, with_q=False):

@@ -82,6 +82,10 @@ enum {
   DFD_GEMM_STREAM_OUT = 1,  /* C (and the K/V export) is written once and not re-read soon by this GPU's caches' standards:
                                store it non-temporally so that it does not evict the operand panels from L2 (tuned bf16
                                kernels; ignored elsewhere) */
+  DFD_GEMM_SPARE_IF_FREE = 2, /* the spare compute units (bits 8..15) are left free only where that costs no extra round of
+                               tiles for this shape (ViT-B/16's c_proj: 5 rounds on 224 CUs as on 256; ViT-L/14's: 5 instead
+                               of 4, so there the kernel takes every CU).  Without the bit the request is binding (the
+                               window a collective needs beside the encoder) */
   DFD_GEMM_TILE_BLOCKS_SHIFT = 16, /* bits 16..19: 0 = the persistent kernel chooses its tile height; 7 / 8 = force 224- /
                                256-row tiles (tests, tuning) */
   DFD_GEMM_SPARE_CUS_SHIFT = 8 /* bits 8..15: compute units the persistent kernel leaves free (its grid is one workgroup
