@@ -267,3 +267,36 @@ def test_isa_lint_no_register_scalar_offset_on_wide_stores():
     lint = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lint)
     assert lint.main([]) == 0
+
+
+def test_detector_zero_grad_matches_module_semantics():
+    """`Detector.zero_grad` walks a cached parameter list instead of the module tree: same effect as `nn.Module.zero_grad`
+    for both `set_to_none` forms, a gradient on a frozen parameter is cleared too, a parameter unfrozen later is seen, and
+    a deep copy (the trainer's teacher) has a list of its own."""
+    import copy
+    from dfd_clip_amd.detector import Detector
+    case = build_case("tiny")
+    det = Detector(case["cfg"], case["T"], None, precision="fp32")
+    params = list(det.parameters())
+    trainable = [p for p in params if p.requires_grad]
+    frozen = [p for p in params if not p.requires_grad]
+    assert trainable and frozen
+    for p in params:
+        p.grad = torch.ones_like(p)
+    det.zero_grad()
+    assert all(p.grad is None for p in params)
+    for p in trainable:
+        p.grad = torch.ones_like(p)
+    det.zero_grad(set_to_none=False)
+    assert all(p.grad is not None and not p.grad.any() for p in trainable)
+    frozen[0].requires_grad_(True)  # unfrozen after the list was built
+    frozen[0].grad = torch.ones_like(frozen[0])
+    det.zero_grad()
+    assert frozen[0].grad is None
+    twin = copy.deepcopy(det)
+    for p in twin.parameters():
+        p.grad = torch.ones_like(p)
+    for p in det.parameters():
+        p.grad = torch.ones_like(p)
+    twin.zero_grad()
+    assert all(p.grad is None for p in twin.parameters()) and all(p.grad is not None for p in det.parameters())
