@@ -31,6 +31,8 @@ from .decoder import Decoder
 from .encoder import RuntimeStateMixin, VisionTransformer
 from .weights import ARCHS, resolve_layer_indices
 
+_ENC_STREAMS = {}  # device -> the process's high-priority encoder stream (`Detector._encode`)
+
 CLIP_CACHE = os.path.expanduser("~/.cache/clip")  # where the reference's downloader leaves checkpoints (clip/clip.py:94)
 
 
@@ -422,8 +424,12 @@ class Detector(RuntimeStateMixin, nn.Module):
         cur = torch.cuda.current_stream()
         if self._enc_stream is None:
             # high priority: the encoder's GEMM workgroups are dispatched first, the decoder's small
-            # latency-bound kernels take what is left over (tile-round tails)
-            self._enc_stream = torch.cuda.Stream(priority=-1)
+            # latency-bound kernels take what is left over (tile-round tails).  ONE such stream per device for all
+            # detectors of the process: with a stream of its own per model, the third model built in a process (bench.py's
+            # secondary legs) ran its pipelined pass 19 % slower than alone, 30.7 against 25.7 ms, as if its two streams
+            # no longer overlapped (HIP maps streams onto a few hardware queues; measured with tools/lab/sec_fp8_probe.py)
+            self._enc_stream = _ENC_STREAMS.setdefault((x.device.type, x.device.index), None) or torch.cuda.Stream(device=x.device, priority=-1)
+            _ENC_STREAMS[(x.device.type, x.device.index)] = self._enc_stream
         E = self._enc_stream
         for ev in self._pipe_events[slot]:
             E.wait_event(ev)
