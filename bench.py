@@ -25,9 +25,10 @@ Prints ONE JSON line on rank 0 with the whole-job clips/s plus
 Host figures: `host_enqueue_ms_each_step` is the wall time the host spent inside each timed step's calls,
 `host_enqueue_ms_median` their median, `host_enqueue_ms_per_step` their mean over the steps in which the host did not
 block, `host_queue_stall_ms_total` the time of those in which it did, and `host_cpu_ms_per_step` the CPU seconds of all
-threads over the region (the runtime's spinning included).  The stall: the third kernel-by-kernel step in a row blocks
-for 70-140 ms, wherever it sits in the region (the runtime recycles a stream's completion signals after a few hundred
-commands and waits for the stream to drain).  At the END of the region that costs nothing — the GPU has the remaining
+threads over the region (the runtime's spinning included).  The stall: one of the kernel-by-kernel steps blocks for
+70-160 ms in most runs, wherever they sit in the region and whether there are two or three of them (a burst of a few
+hundred launches and event records on a stream the host is many steps ahead on; the runtime waits for the stream to
+drain).  At the END of the region that costs nothing — the GPU has the remaining
 work queued — which is why the profiled steps are the last three (placed third to fifth they cost 5-18 % of the
 measured rate; keeping the host four steps behind with a blocking-sync event per step was worse still: 864-873 ->
 721-779 clips/s).
