@@ -143,16 +143,33 @@ __global__ __launch_bounds__(TT == 128 ? 256 : 512, TT == 128 ? 2 : 1) void gemm
       }
 }
 
-__global__ void tn_slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int splits) {
-  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= n) return;
-  f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
-  for (int z = 1; z < splits; ++z) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + (int64_t)z * n + i);
+// out[i] = Σ_z slabs[z][i] in a FIXED order: lane group g (of ZG) sums the slabs z ≡ g (mod ZG) in ascending z, the
+// groups are then added in ascending g.  (One thread walking all slabs was latency-bound: 85 dependent loads, 23 us for
+// 67 MB; four independent walks per output quadruple the loads in flight.)
+constexpr int ZG = 4;
+__global__ __launch_bounds__(64 * ZG) void tn_slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int splits) {
+  __shared__ f32x4 part[ZG][64];
+  const int t = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = ((int64_t)blockIdx.x * 64 + t) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    for (int z = g; z < splits; z += ZG) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + (int64_t)z * n + i);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s[e] += v[e];
+      for (int e = 0; e < 4; ++e) s[e] += v[e];
+    }
   }
-  *reinterpret_cast<f32x4*>(out + i) = s;
+  part[g][t] = s;
+  __syncthreads();
+  if (g == 0 && i < n) {
+#pragma unroll
+    for (int k = 1; k < ZG; ++k) {
+      const f32x4 v = part[k][t];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += v[e];
+    }
+    *reinterpret_cast<f32x4*>(out + i) = s;
+  }
 }
 
 }  // namespace
@@ -199,7 +216,7 @@ int dfd_gemm_tn_launch(const void* A, int64_t lda, const void* B, int64_t ldb, f
   }
   DFD_CHECK_LAUNCH("dfd_gemm_at_b(tn)");
   const int64_t n = (int64_t)Ma * Nb;
-  hipLaunchKernelGGL(tn_slab_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, slabs, C, n, splits);
+  hipLaunchKernelGGL(tn_slab_reduce_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(64 * ZG), 0, st, slabs, C, n, splits);
   DFD_CHECK_LAUNCH("dfd_gemm_at_b(reduce)");
   return DFD_OK;
 }
