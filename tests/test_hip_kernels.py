@@ -312,7 +312,7 @@ def test_persistent_gemm_variants_are_bit_identical(capi, M, N, K, epi):
     assert_close(base[0][rows], ref, 1e-4, 2 ** -8, "256-row tiles")
     assert all(torch.isfinite(t.float()).all() for t in base), "a tile or an export row was not written"
     for opts in (dict(tile_blocks=7), dict(), dict(tile_blocks=8, stream_out=True), dict(tile_blocks=7, stream_out=True, spare_cus=32),
-                 dict(spare_cus=100)):
+                 dict(spare_cus=100), dict(spare_cus=32, spare_if_free=True), dict(spare_cus=120, spare_if_free=True)):
         got = run(**opts)
         for x, y in zip(base, got):
             assert torch.equal(x, y), opts
